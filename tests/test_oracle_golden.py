@@ -1,0 +1,202 @@
+"""Pins the CPU oracle (oracle/eig_oracle.py) against the golden vectors the reference's own functions
+produced in the dev container (tests/golden/make_golden.py) and against LAPACK-independent
+known-answer tests.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+
+# ---- attention ------------------------------------------------------------------------------
+@pytest.mark.parametrize("case,rtol", [("a", 2e-5), ("b", 1e-4), ("c", 2e-3)])
+def test_softmax_eta_matches_reference(golden, case, rtol):
+    g = golden("attention")
+    with np.errstate(over="ignore"):
+        got = O.eta_softmax(g[f"x_{case}"], g[f"w_{case}"], g[f"b_{case}"], int(g["d_qk"]), int(g["H"]), int(g["D"]))
+    want = g[f"softmax_{case}"]
+    assert got.shape == want.shape == (int(g["B"]), int(g["L"]) - 1, int(g["H"]), 1)
+    assert got.dtype == np.float64
+    # eta carries exp(m_t - m_{t+1}) with m in fp32 (eval_eig.py:86-88): its relative noise is
+    # |m| * 6e-8, and torch-CPU vs NumPy fp32 GEMMs sum in different orders.  Case c has |scores| of
+    # several hundred (and overflows to inf in places), hence the magnitude-scaled tolerances.
+    finite = np.isfinite(want)
+    assert np.array_equal(finite, np.isfinite(got))
+    np.testing.assert_allclose(got[finite], want[finite], rtol=rtol, atol=0)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_linear_eta_matches_reference(golden, case):
+    g = golden("attention")
+    args = (g[f"x_{case}"], g[f"w_{case}"], g[f"b_{case}"], int(g["d_qk"]), int(g["H"]), int(g["D"]))
+    got = O.eta_linear(*args)
+    want = g[f"linear_{case}"]
+    assert got.shape == want.shape and got.dtype == np.float64
+    np.testing.assert_allclose(got, want, rtol=2e-6)
+    np.testing.assert_allclose(O.eta_linear_streaming(*args), want, rtol=2e-6)
+
+
+@pytest.mark.parametrize("fn", ["exp", "elu", "softplus", "sigmoid"])
+@pytest.mark.parametrize("use_off", [0, 1])
+def test_norm_eta_matches_reference(golden, fn, use_off):
+    g = golden("norm_attention")
+    got = O.eta_norm(g["x"], g["w"], g["b"], g["offset"] if use_off else None, fn,
+                     int(g["d_qk"]), int(g["H"]), int(g["D"]))
+    want = g[f"eta_{fn}_{use_off}"]
+    assert got.shape == want.shape
+    finite = np.isfinite(want)
+    assert np.array_equal(finite, np.isfinite(got))
+    np.testing.assert_allclose(got[finite], want[finite], rtol=5e-5)
+
+
+def test_norm_eta_unknown_fn_raises(golden):
+    g = golden("norm_attention")
+    with pytest.raises(RuntimeError, match="normalization function tanh not implemented!"):
+        O.eta_norm(g["x"], g["w"], g["b"], None, "tanh", 8, 2, 16)
+
+
+# ---- mamba2 ---------------------------------------------------------------------------------
+def test_mamba2_lambda_matches_reference(golden):
+    g = golden("mamba2")
+    got = O.lambda_mamba2(g["x"], g["w"], g["b"], g["dt_bias"], g["A_log"], int(g["d_inner"]),
+                          int(g["ngroups"]), int(g["d_state"]), int(g["nheads"]))
+    assert got.dtype == np.float32 and got.shape == g["lam"].shape
+    np.testing.assert_allclose(got, g["lam"], rtol=3e-6, atol=1e-7)
+    got = O.lambda_mamba2_lti(g["x"], g["A"], g["beta"])
+    assert got.dtype == np.float32 and got.shape == g["lam_lti"].shape
+    np.testing.assert_allclose(got, g["lam_lti"], rtol=1e-6)
+
+
+# ---- SSM ------------------------------------------------------------------------------------
+def _layers(g, fam, names):
+    return [{n: g[f"{fam}_{i}_{n}"] for n in names} for i in range(2)]
+
+
+def test_ssm_closed_forms_match_reference(golden):
+    g = golden("ssm")
+    s5 = _layers(g, "s5", ["Lambda_re", "Lambda_im", "log_step"])
+    lru = _layers(g, "lru", ["nu_log", "theta_log"])
+    for i in range(2):
+        np.testing.assert_allclose(O.eigvals_ssm("s5", s5, i, 1, 16), g[f"s5_{i}_eig"], rtol=1e-14)
+        np.testing.assert_allclose(O.eigvals_ssm("lru", lru, i, 1, 16), g[f"lru_{i}_eig"], rtol=1e-14)
+    assert bool(g["unknown_returns_none"]) and O.eigvals_ssm("s6", s5, 0, 1, 16) is None
+
+
+def test_s4_dplr_and_eigs_match_reference(golden):
+    g = golden("ssm")
+    s4 = _layers(g, "s4", ["log_step", "Lambda_re", "Lambda_im", "P", "B", "C"])
+    for i in range(2):
+        Lam, Pv, Bv, Ct, step = O.s4_column_inputs(s4[i], 1)
+        Ab, Bb, Cb = O.discrete_dplr(Lam, Pv, Pv, Bv, Ct, step, int(g["SEQ"]))
+        np.testing.assert_allclose(Ab, g[f"s4_{i}_Ab"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(Bb, g[f"s4_{i}_Bb"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(Cb, g[f"s4_{i}_Cb"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(O.s4_dplr_ab(Lam, Pv, step), g[f"s4_{i}_Ab"], rtol=1e-11, atol=1e-12)
+        w = O.eigvals_ssm("s4", s4, i, 1, int(g["SEQ"]))
+        assert w.shape == (int(g["N"]), 1)
+        assert O.max_abs_dlambda(w[:, 0], g[f"s4_{i}_eig"][:, 0]) < 1e-11
+
+
+def test_s4_cayley_known_answer():
+    """LAPACK-independent structure check: Ab = (g - A)^{-1} (g + A) with g = 2/step, so
+    eig(Ab) = (g + a)/(g - a) for a in eig(A)."""
+    rng = np.random.default_rng(5)
+    n = 24
+    Lam = -np.abs(rng.standard_normal(n)) + 1j * rng.standard_normal(n) * 4
+    P = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.5
+    step = 0.037
+    Ab = O.s4_dplr_ab(Lam, P, step)
+    A = np.diag(Lam) - np.outer(P, P.conj())
+    gg = 2.0 / step
+    np.testing.assert_allclose(Ab, np.linalg.solve(gg * np.eye(n) - A, gg * np.eye(n) + A), rtol=1e-10, atol=1e-12)
+    a = np.linalg.eigvals(A)
+    assert O.max_abs_dlambda((gg + a) / (gg - a), np.linalg.eigvals(Ab)) < 1e-10
+
+
+def test_hippo_dplr_reconstructs_hippo():
+    """make_dplr_hippo: V diag(Lambda) V^H - P P^T == HiPPO-LegS (models/common.py:215-241)."""
+    n = 16
+    Lam, P, B, V, B_orig = O.make_dplr_hippo(n)
+    A, p, b = O.make_nplr_hippo(n)
+    np.testing.assert_allclose(V @ np.diag(Lam) @ V.conj().T - np.outer(p, p), A, atol=1e-10)
+    np.testing.assert_allclose(V.conj().T @ p, P, atol=1e-12)
+    assert np.allclose(Lam.real, -0.5)
+
+
+# ---- thresholds + report --------------------------------------------------------------------
+def test_threshold_analysis_matches_reference(golden):
+    g = golden("thresholds")
+    pct = O.threshold_analysis(g["vals"], O.THRESHOLDS_RADIUS, 3, 2, 8)
+    np.testing.assert_array_equal(pct, g["pct"])
+    np.testing.assert_array_equal(O.threshold_analysis(g["vals2"], O.THRESHOLDS_RADIUS, 3, 2, 8), g["pct_init"])
+    with np.errstate(invalid="ignore"):
+        np.testing.assert_array_equal(O.threshold_analysis(0 * g["vals"], O.THRESHOLDS_PHASE, 3, 2, 8), g["pct_phase"])
+    # edge values are double counted (Q12): column with values exactly on all six edges
+    assert pct[:, 0, 0, 0].sum() > 100.0
+
+
+def test_threshold_analysis_ssm_matches_reference(golden):
+    g = golden("thresholds")
+    rad, ph = O.radius(g["cplx"]), O.phase_deg(g["cplx"])
+    np.testing.assert_array_equal(O.threshold_analysis_ssm(rad, O.THRESHOLDS_RADIUS, 3), g["pct_s"])
+    np.testing.assert_array_equal(O.threshold_analysis_ssm(rad * 0.5, O.THRESHOLDS_RADIUS, 3), g["pct_s_init"])
+    np.testing.assert_array_equal(O.threshold_analysis_ssm(ph, O.THRESHOLDS_PHASE, 3), g["pct_sp"])
+    np.testing.assert_array_equal(O.threshold_analysis_ssm(ph * 0.5, O.THRESHOLDS_PHASE, 3), g["pct_sp_init"])
+
+
+def test_report_text_matches_reference(golden, tmp_path):
+    g = golden("thresholds")
+    p = tmp_path / "percentage_file.txt"
+    pct, pct_init = g["pct"], g["pct_init"]
+    O.write_percentage_file(str(p), O.THRESHOLDS_RADIUS, pct, pct_init, pct.mean(axis=1), pct_init.mean(axis=1),
+                            pct.std(axis=1), pct_init.std(axis=1))
+    assert p.read_text() == str(g["report"])
+    O.write_percentage_file_ssm(str(p), O.THRESHOLDS_RADIUS, O.THRESHOLDS_PHASE, g["pct_s"], g["pct_s_init"],
+                                g["pct_sp"], g["pct_sp_init"])
+    assert p.read_text() == str(g["report_ssm"])
+
+
+# ---- analytic known answers (no LAPACK in the expected value) -----------------------------------
+def test_linear_eta_constant_sequence_limit():
+    """Constant tokens: nu_t = (t+1) c  =>  eta_t = (t+1)/(t+2)."""
+    rng = np.random.default_rng(0)
+    D, d_qk, H, L = 8, 4, 2, 9
+    x = np.tile(rng.standard_normal((1, 1, D)).astype(np.float32), (2, L, 1))
+    w = rng.standard_normal((2 * d_qk + D, D)).astype(np.float32)
+    b = rng.standard_normal(2 * d_qk + D).astype(np.float32)
+    eta = O.eta_linear(x, w, b, d_qk, H, D)
+    t = np.arange(L - 1)
+    np.testing.assert_allclose(eta[0, :, 0, 0], (t + 1) / (t + 2), rtol=1e-6)
+
+
+def test_softmax_eta_constant_sequence_limit():
+    """Constant tokens with score s: m_t = max(s, 0) for t < L-1 and s for t = L-1 (Q5);
+    nu_t = (t+1) exp(s - m_t) + (L-1-t) (Q4)."""
+    rng = np.random.default_rng(1)
+    D, d_qk, H, L = 8, 4, 1, 7
+    x = np.tile(rng.standard_normal((1, 1, D)).astype(np.float32), (1, L, 1))
+    w = rng.standard_normal((2 * d_qk + D, D)).astype(np.float32)
+    b = np.zeros(2 * d_qk + D, np.float32)
+    qkv = O.linear_f32(x[0, 0], w, b)
+    s = float(np.dot(qkv[:d_qk].astype(np.float32), qkv[d_qk:2 * d_qk].astype(np.float32)))
+    t = np.arange(L)
+    m = np.where(t < L - 1, max(s, 0.0), s)
+    nu = (t + 1) * np.exp(s - m) + (L - 1 - t)
+    want = nu[:-1] / nu[1:] * np.exp(m[:-1] - m[1:])
+    got = O.eta_softmax(x, w, b, d_qk, H, D)[0, :, 0, 0]
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+
+
+def test_dense_eig_similarity_known_spectrum():
+    rng = np.random.default_rng(64)
+    n = 12
+    lam = np.exp((-0.5 + 1j * rng.uniform(0, 20, n // 2)) * 0.05)
+    lam = np.concatenate([lam, lam.conj()])
+    # real matrix with that spectrum: block diagonal rotations under a well-conditioned similarity
+    Dm = np.zeros((n, n))
+    for i, z in enumerate(lam[: n // 2]):
+        Dm[2 * i:2 * i + 2, 2 * i:2 * i + 2] = [[z.real, z.imag], [-z.imag, z.real]]
+    V = np.eye(n) + 0.1 * rng.standard_normal((n, n)) / np.sqrt(n)
+    A = V @ Dm @ np.linalg.inv(V)
+    assert O.max_abs_dlambda(O.eigvals_dense(A), lam) < 1e-12
