@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Benchmark of the eigenvalue-analysis hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): S5-sized dense spectra -- d_state = 64, seq_len = 1024, batch = 512, i.e.
+524,288 real fp64 64x64 state-transition matrices PER GPU (weak scaling: every rank owns that many; the matrices
+are independent, so there is no data-path collective, only the single all-gather of the spectra at N > 1).
+One "step" = one pass of the hot path over the whole resident batch: Householder-Hessenberg + Francis QR
+(egs_eig_general_batched through the C ABI) [+ all_gather of the spectra when N > 1].
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (metric = eigen-spectra/sec, plus max |dlambda| vs the oracle after matching).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "task-level-insights-from-eigenvalues-across-sequence-models_amd"
+
+FP64_PEAK_TFLOPS = 78.6        # MI355X fp64 vector = matrix peak (datasheet)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def gen_known_spectrum(cnt, n, gen, device):
+    """Real matrices Q (D + N) Q^T with S5-style eigenvalues exp((-0.5 + i w) dt) in conjugate pairs (SURVEY.md 8(d)
+    C2): D = 2x2 rotation-scaling blocks, N strictly block-upper (non-normal part), Q = three Householder reflectors.
+    Returns (a [cnt,n,n] float64, lam [cnt,n] complex128)."""
+    npair = n // 2
+    om = torch.rand((cnt, npair), generator=gen, device=device, dtype=torch.float64) * 40.0
+    lo, hi = np.log(1e-3), np.log(1e-1)
+    dt = torch.exp(torch.rand((cnt, npair), generator=gen, device=device, dtype=torch.float64) * (hi - lo) + lo)
+    lam = torch.exp(torch.complex(-0.5 * dt, om * dt))
+    a = torch.randn((cnt, n, n), generator=gen, device=device, dtype=torch.float64).triu_(2) * (0.3 / np.sqrt(n))
+    idx = torch.arange(npair, device=device) * 2
+    a[:, idx, idx] = lam.real
+    a[:, idx + 1, idx + 1] = lam.real
+    a[:, idx, idx + 1] = lam.imag
+    a[:, idx + 1, idx] = -lam.imag
+    for _ in range(3):
+        u = torch.randn((cnt, n, 1), generator=gen, device=device, dtype=torch.float64)
+        u = u / torch.linalg.vector_norm(u, dim=1, keepdim=True)
+        a = a - 2.0 * u @ (u.transpose(1, 2) @ a)
+        a = a - 2.0 * (a @ u) @ u.transpose(1, 2)
+    return a, torch.cat([lam, lam.conj()], dim=1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nmat", type=int, default=512 * 1024, help="matrices per GPU (batch 512 x seq_len 1024)")
+    ap.add_argument("--n", type=int, default=64, help="d_state")
+    ap.add_argument("--matrices", choices=["s5", "randn"], default="s5")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the eigenvalue-analysis path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    pkg = importlib.import_module(PKG)
+    ops, egs_dist = pkg.ops, pkg.dist
+    import oracle as O
+
+    n, nmat = args.n, args.nmat
+    gen = torch.Generator(device=device)
+    gen.manual_seed(64 + rank)
+    a = torch.empty((nmat, n, n), dtype=torch.float64, device=device)
+    lam_sample = None
+    gchunk = 16384
+    for m0 in range(0, nmat, gchunk):
+        cnt = min(gchunk, nmat - m0)
+        if args.matrices == "s5":
+            blk, lam = gen_known_spectrum(cnt, n, gen, device)
+            if m0 == 0:
+                lam_sample = lam[:512].cpu().numpy()
+        else:
+            blk = torch.randn((cnt, n, n), generator=gen, device=device, dtype=torch.float64) / np.sqrt(n)
+        a[m0:m0 + cnt] = blk
+        del blk
+    ws_bytes = pkg._capi.lib().egs_eig_workspace_bytes(pkg._capi.EGS_F64, nmat, n)
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
+
+    def step():
+        w, info = ops.eig_general_batched(a, workspace=workspace)
+        if world > 1:
+            w = _gather(w)
+        return w, info
+
+    def _gather(w):
+        import torch.distributed as dist
+        out = torch.empty((world * nmat, n), dtype=torch.complex128, device=device)
+        dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(w))   # the ONE collective of the path
+        return out
+
+    for _ in range(args.warmup):
+        w, info = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w, info = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = nmat * world / (elapsed / args.steps)
+
+    # ---- per-kernel timing (HIP events on the launch stream) for the roofline object ----
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    hq_ms, hs_ms = [], []
+    chunk = min(nmat, 16384)
+    hbuf = torch.empty((chunk, n, n), dtype=torch.float64, device=device)
+    lib = pkg._capi.lib()
+    import ctypes
+    wtmp = torch.empty((chunk, n), dtype=torch.complex128, device=device)
+    itmp = torch.empty((chunk,), dtype=torch.int32, device=device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nlaunch = 0
+    for rep in range(2):
+        for m0 in range(0, nmat, chunk):
+            cnt = min(chunk, nmat - m0)
+            ev[0].record()
+            lib.egs_hessenberg_batched(ctypes.c_void_p(a[m0].data_ptr()), cnt, n, n, n * n,
+                                       ctypes.c_void_p(hbuf.data_ptr()), stream)
+            ev[1].record()
+            lib.egs_hseqr_batched(ctypes.c_void_p(hbuf.data_ptr()), cnt, n, ctypes.c_void_p(wtmp.data_ptr()),
+                                  ctypes.c_void_p(itmp.data_ptr()), stream)
+            ev[2].record()
+            ev[2].synchronize()
+            if rep == 1 and cnt == chunk:
+                hs_ms.append(ev[0].elapsed_time(ev[1]))
+                hq_ms.append(ev[1].elapsed_time(ev[2]))
+                nlaunch += 1
+    hq_avg = float(np.mean(hq_ms))
+    hs_avg = float(np.mean(hs_ms))
+    # algorithmic work per matrix: (10/3) n^3 Hessenberg + 10 n^3 QR flops; n^2*8 + 16 n bytes
+    qr_flops = 10.0 * n ** 3 * chunk
+    hs_flops = (10.0 / 3.0) * n ** 3 * chunk
+    achieved_tf = qr_flops / (hq_avg * 1e-3) / 1e12
+    roofline = {
+        "bound": "mfma", "kernel": "hqr_real_kernel", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": None,
+        "note": "fp64 (vector = matrix peak); algorithmic 10 n^3 flops per matrix, %d matrices per launch" % chunk,
+        "avg_launch_ms": hq_avg, "launches_timed": nlaunch,
+        "hess_kernel": {"kernel": "hess_real_kernel", "avg_launch_ms": hs_avg,
+                        "achieved_tflops": hs_flops / (hs_avg * 1e-3) / 1e12},
+        "hbm_gbs_algorithmic": (n * n * 8 + 16 * n) * chunk / ((hq_avg + hs_avg) * 1e-3) / 1e9,
+    }
+
+    # ---- parity: GPU spectra vs the known spectrum and vs LAPACK on a sample ----
+    info_bad = int((info != 0).sum().item())
+    w_host = w[:512].cpu().numpy() if rank == 0 else None
+    result = None
+    if rank == 0:
+        a_sample = a[:512].cpu().numpy()
+        d_lapack = O.max_abs_dlambda(w_host, O.eigvals_dense(a_sample))
+        d_known = O.max_abs_dlambda(w_host, lam_sample) if lam_sample is not None else None
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline(a, args.cpu_seconds, O)
+        result = {
+            "metric": "eigen-spectra/sec (batch x seq_len x d_state matrices) + max |dlambda| vs reference",
+            "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: S5 d_state=64, seq_len=1024, batch=512 -> 524288 dense 64x64 fp64 matrices per GPU "
+                                   "(known S5-style spectrum under a non-normal orthogonal similarity)",
+                       "d_state": n, "matrices_per_gpu": nmat, "matrix_kind": args.matrices,
+                       "parallelism": "matrix-sharded x%d, one all_gather of spectra" % world},
+            "max_abs_dlambda_vs_lapack": d_lapack, "max_abs_dlambda_vs_known": d_known, "unconverged": info_bad,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if cpu is not None:
+            result["speedup_vs_cpu_1core"] = value / cpu["value"]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline(a, budget_s, O):
+    """The oracle's dense path (np.linalg.eigvals -> LAPACK dgeev, the same third-party arithmetic the reference
+    calls at analysis/eval_eig.py:296) timed on this node's host cores on a bounded sample of the same matrices."""
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:
+        limiter = None
+    done, spent = 0, 0.0
+    blk = 1024
+    while spent < budget_s and done + blk <= min(a.shape[0], 65536):
+        host = a[done:done + blk].cpu().numpy()
+        t0 = time.perf_counter()
+        O.eigvals_dense(host)
+        spent += time.perf_counter() - t0
+        done += blk
+    if limiter is not None:
+        limiter.unregister() if hasattr(limiter, "unregister") else None
+    return {"value": done / spent, "unit": "spectra/s", "cores": 1, "kind": "port",
+            "sample": "first %d of the benchmark's own matrices, stacked np.linalg.eigvals, 1 thread, %.1f s"
+                      % (done, spent),
+            "host_cpu_count": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/* eigspec.h -- C ABI of the MI355X-native eigenvalue-analysis hot path (libeigspec_hip.so).
+ *
+ * Drop-in boundary for the reference's analysis/eval_eig.py (all file:line citations are relative to the
+ * reference repository root).  The reference has no FFI of its own: its hot path bottoms out in torch
+ * (nn.Linear / einsum on "cuda"), JAX and NumPy/LAPACK calls.  Each entry point below replaces one such
+ * call site; the Python host code (the package's analysis/eval_eig.py mirror) binds them with ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / HIP types in the signatures (egs_stream_t is a
+ *     hipStream_t passed as void*; NULL = the default stream).
+ *   - every function returns an int status: 0 = ok, -k = argument k (1-based) is invalid (LAPACK style),
+ *     EGS_ERR_RUNTIME = a HIP runtime call failed (see egs_last_error_string()).
+ *   - the caller owns every buffer.  All data pointers are DEVICE pointers unless stated otherwise.  The
+ *     library never allocates or frees user-visible memory; scratch space is passed in as `workspace`
+ *     (size from the matching *_workspace_bytes query; host-only, no GPU needed).
+ *   - calls are asynchronous on `stream` unless stated otherwise; outputs are valid after the stream
+ *     is synchronised.  One host thread per stream.
+ *   - complex numbers are interleaved (re, im) pairs of the stated real type.
+ */
+#ifndef EIGSPEC_H
+#define EIGSPEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* egs_stream_t;
+
+#define EGS_VERSION 100          /* 0.1.0 */
+#define EGS_ERR_RUNTIME (-1000)
+
+/* element types for matrices / value arrays */
+#define EGS_F32 0
+#define EGS_F64 1
+#define EGS_C64 2
+#define EGS_C128 3
+
+/* ---- diagnostics ------------------------------------------------------------------------------- */
+int egs_version(void);
+/* Thread-local, NUL-terminated description of the last failure on the calling thread ("" if none). */
+const char* egs_last_error_string(void);
+
+typedef struct egs_device_props {
+    int compute_units;
+    int wavefront_size;
+    int lds_bytes_per_block;      /* max dynamic LDS a block of ours may request */
+    int clock_khz;
+    int64_t hbm_bytes;
+    char arch[32];                /* e.g. "gfx950" */
+} egs_device_props;
+/* Synchronous; fills *out (HOST pointer) for HIP device `device`. */
+int egs_device_props_query(int device, egs_device_props* out);
+
+/* ---- K1: diagonal SSM spectra (closed forms) ---------------------------------------------------
+ * Replaces get_eigvals_ssm "lru" (analysis/eval_eig.py:318-329; models/lru.py:88) and "s5"
+ * (analysis/eval_eig.py:303-316: always ZOH, Lambda_re never clipped -- quirk Q10).
+ *   mode 0 (lru): lambda[i] = exp(-exp(p0[i]) + i*exp(p1[i]))           p0 = nu_log, p1 = theta_log, p2 unused
+ *   mode 1 (s5) : lambda[i] = exp((p0[i] + i*p1[i]) * exp(p2[i]))        p0 = Lambda_re, p1 = Lambda_im, p2 = log_step
+ * p*: double[n]; out: complex128[n].  (The host mirror down-casts to complex64 when asked to emulate JAX's default.) */
+#define EGS_DIAG_LRU 0
+#define EGS_DIAG_S5_ZOH 1
+int egs_diag_ssm_lambda(int mode, const double* p0, const double* p1, const double* p2, int64_t n,
+                        double* out_lambda, egs_stream_t stream);
+
+/* ---- S4: bilinear-discretised DPLR state matrix --------------------------------------------------
+ * Replaces discrete_DPLR's Ab (analysis/eval_eig.py:254-273, twin models/s4.py:16-40) with Q = P as
+ * called at analysis/eval_eig.py:294, for `nmat` independent feature columns at once.  The discarded
+ * Bb/Cb (matrix_power, inv -- quirk Q18) are not computed.  Lambda_re is clipped to <= -1e-4 inside
+ * (analysis/eval_eig.py:288, quirk Q11); step = exp(log_step).
+ *   lambda_re, lambda_im, p_re, p_im : double[nmat, n]      log_step : double[nmat]
+ *   ab : complex128[nmat, n, n] row-major, Ab = A1 * A0. */
+int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const double* p_re,
+                      const double* p_im, const double* log_step, int64_t nmat, int n,
+                      double* ab, egs_stream_t stream);
+
+/* ---- K5: batched dense non-symmetric eigenvalues -------------------------------------------------
+ * Replaces np.linalg.eigvals (LAPACK ?geev, analysis/eval_eig.py:296), generalised from one matrix per
+ * layer to a batch.  Householder reduction to Hessenberg form + shifted QR (Francis double-shift for real
+ * input, single-shift for complex input), eigenvalues only.
+ *   a      : [nmat] matrices, element (i,j) of matrix m at a[m*stride + i*lda + j] (elements of `dtype`,
+ *            EGS_F64 or EGS_C128; row-major).  Not modified.
+ *   w      : complex128[nmat, n] eigenvalues, in the order the deflation produced them (sort to compare).
+ *   info   : int32[nmat]; 0 = converged, k > 0 = QR failed to deflate with k eigenvalues outstanding
+ *            (their slots hold NaN), as LAPACK's xHSEQR info.
+ *   workspace : device scratch of egs_eig_workspace_bytes(dtype, nmat, n) bytes, 256-byte aligned.
+ * n <= 64 real and n <= 64 complex run LDS-resident (one wavefront per matrix); larger n (<= 1024) run
+ * one workgroup per matrix out of the workspace copy. */
+size_t egs_eig_workspace_bytes(int dtype, int64_t nmat, int n);
+int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int lda, int64_t stride,
+                            double* w, int32_t* info, void* workspace, size_t workspace_bytes,
+                            egs_stream_t stream);
+
+/* The two stages of the real LDS-resident solver (dtype EGS_F64, n <= 64), exposed separately like LAPACK's
+ * xGEHRD / xHSEQR so that callers (and bench.py) can time or reuse them individually.
+ *   egs_hessenberg_batched : a -> h, double[nmat, n, n] row-major upper-Hessenberg (exact zeros below the
+ *                            subdiagonal); same eigenvalues as a.
+ *   egs_hseqr_batched      : h (as produced above) -> w, info. */
+int egs_hessenberg_batched(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h,
+                           egs_stream_t stream);
+int egs_hseqr_batched(const double* h, int64_t nmat, int n, double* w, int32_t* info, egs_stream_t stream);
+
+/* ---- K2: Mamba-2 per-token transition scalars -----------------------------------------------------
+ * Replaces get_eig_mamba2 (analysis/eval_eig.py:176-190): only the last `nheads` rows of in_proj.weight
+ * are used (models/mamba.py:63-64), fused with softplus(dt + dt_bias) (torch threshold 20) and
+ * exp(dt * -exp(A_log)).  fp32 throughout (quirk Q7).
+ *   x : float[ntok, ldx] (first D columns used)   w_dt : float[nheads, D]   b_dt : float[nheads] or NULL
+ *   dt_bias, a_log : float[nheads]                out : float[ntok, nheads] */
+int egs_mamba2_lambda(const float* x, int64_t ntok, int d_model, int64_t ldx, const float* w_dt,
+                      const float* b_dt, const float* dt_bias, const float* a_log, int nheads,
+                      float* out, egs_stream_t stream);
+/* Replaces get_eig_mamba2_LTI (analysis/eval_eig.py:192-205): exp(beta * -softplus(A)) broadcast to
+ * [ntok, nheads] (quirk Q19: the reference's dead in_proj GEMM is not run). */
+int egs_mamba2_lti_lambda(const float* a_param, const float* beta, int nheads, int64_t ntok,
+                          float* out, egs_stream_t stream);
+
+/* ---- K3/K4: attention normaliser ratios -------------------------------------------------------------
+ * Replace get_eig_att_linear (analysis/eval_eig.py:97-135) and get_eig_att_softmax (:43-95).  Inputs are
+ * the block output x and the q/k rows of Wqkv (models/attention.py:120-122: rows [0, d_qk) = q,
+ * [d_qk, 2 d_qk) = k, split "(two h d)"); the v rows are never touched.  Neither materialises the
+ * (B, L, L, H) score tensor.
+ *   x : float[B, L, D]   w_qk : float[2*d_qk, D]   b_qk : float[2*d_qk] or NULL   eta : double[B, L-1, H]
+ *   workspace: egs_attn_workspace_bytes(B, L, d_qk, H) bytes (projected q,k in fp32, nu / row max scratch).
+ * linear : nu_t = phi(q_t) . sum_{s<=t} phi(k_s), phi = elu + 1; nu == 0 -> 2e-23 (Q6); eta_t = nu_t / nu_{t+1}.
+ * softmax: scores q_t.k_s (no 1/sqrt(d), Q3); m_t = max(max_{s<=t} score, 0 if t < L-1) (Q5);
+ *          nu_t = sum_{s<=t} exp(score - m_t) + (L-1-t) (Q4); eta_t = nu_t/nu_{t+1} * exp(m_t - m_{t+1}). */
+size_t egs_attn_workspace_bytes(int64_t batch, int64_t seqlen, int d_qk, int num_heads);
+int egs_linattn_eta(const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_qk,
+                    const float* b_qk, int d_qk, int num_heads, double* eta, void* workspace,
+                    size_t workspace_bytes, egs_stream_t stream);
+int egs_softmax_eta(const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_qk,
+                    const float* b_qk, int d_qk, int num_heads, double* eta, void* workspace,
+                    size_t workspace_bytes, egs_stream_t stream);
+
+/* Replaces get_eig_att_norm (analysis/eval_eig.py:137-174): n = exp(-norm_fn(Wn x + b + offset)) in fp32,
+ * n == 0 -> 2e-23, eta_t = n_{t+1} / n_t.  w_n = the last H rows of Wvqkn (models/norm_attention.py:201-203).
+ *   x : float[B, L, D]   w_n : float[H, D]   b_n, offset : float[H] or NULL   eta : double[B, L-1, H] */
+#define EGS_NORM_EXP 0
+#define EGS_NORM_ELU 1
+#define EGS_NORM_SOFTPLUS 2
+#define EGS_NORM_SIGMOID 3
+int egs_normattn_eta(const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_n,
+                     const float* b_n, const float* offset, int norm_fn, int num_heads, double* eta,
+                     egs_stream_t stream);
+
+/* ---- a9/a10: radius / phase + inclusive-edge threshold histograms -----------------------------------
+ * Replaces threshold_analysis (analysis/eval_eig.py:335-362) and threshold_analysis_ssm (:364-391) with the
+ * radius/phase transforms of :605-606, :614-615, :726-727, :734-735 fused in.  Bins (quirk Q12): bin 0 =
+ * [0, e0], bin i = [e_{i-1}, e_i] (both inclusive), last = (e_last, inf); negatives / NaN fall in no bin.
+ *   vals : [outer, T, inner] of `dtype` (EGS_F32/EGS_F64 real, EGS_C64/EGS_C128 complex)
+ *   transform : EGS_HIST_VALUE (real input as is), EGS_HIST_RADIUS, EGS_HIST_PHASE_DEG (complex or real input;
+ *               real input is treated as imag = 0), EGS_HIST_ZERO (0*value, quirk Q13)
+ *   edges : HOST double[nedges] (nedges <= 15)
+ *   pct   : double[nedges+1, outer, inner] = count / T * 100. */
+#define EGS_HIST_VALUE 0
+#define EGS_HIST_RADIUS 1
+#define EGS_HIST_PHASE_DEG 2
+#define EGS_HIST_ZERO 3
+int egs_threshold_hist(const void* vals, int dtype, int transform, int64_t outer, int64_t t_len,
+                       int64_t inner, const double* edges_host, int nedges, double* pct,
+                       egs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIGSPEC_H */

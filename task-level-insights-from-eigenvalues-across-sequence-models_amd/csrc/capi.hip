@@ -1,0 +1,238 @@
+// extern "C" entry points of libeigspec_hip.so (declared in include/eigspec.h).  Argument validation happens
+// here, on the host, before any kernel is launched: a kernel never sees shapes it was not built for.
+#include <stdarg.h>
+#include <string.h>
+
+#include "egs_common.h"
+
+namespace egs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return EGS_ERR_RUNTIME;
+}
+
+// launchers implemented in the kernel translation units
+int diag_ssm_launch(int, const double*, const double*, const double*, int64_t, double*, hipStream_t);
+int mamba2_lambda_launch(const float*, int64_t, int, int64_t, const float*, const float*, const float*, const float*,
+                         int, float*, hipStream_t);
+int mamba2_lti_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
+int normattn_eta_launch(const float*, int64_t, int64_t, int, const float*, const float*, const float*, int, int,
+                        double*, hipStream_t);
+int s4_dplr_launch(const double*, const double*, const double*, const double*, const double*, int64_t, int, double*,
+                   hipStream_t);
+size_t attn_workspace_bytes(int64_t, int64_t, int, int);
+int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, const float*, int, int, double*, void*,
+                    size_t, hipStream_t);
+int threshold_hist_launch(const void*, int, int, int64_t, int64_t, int64_t, const double*, int, double*, hipStream_t);
+size_t eig_real_lds_workspace_bytes(int64_t, int);
+int eig_real_lds_launch(const double*, int64_t, int, int, int64_t, double*, int32_t*, void*, size_t, hipStream_t);
+int hess_real_launch(const double*, int64_t, int, int, int64_t, double*, hipStream_t);
+int hqr_real_launch(const double*, int64_t, int, double*, int32_t*, hipStream_t);
+size_t eig_cplx_workspace_bytes(int64_t, int);
+int eig_cplx_launch(const void*, bool, int64_t, int, int, int64_t, double*, int32_t*, void*, size_t, hipStream_t);
+
+}  // namespace egs
+
+using namespace egs;
+
+extern "C" {
+
+int egs_version(void) { return EGS_VERSION; }
+
+const char* egs_last_error_string(void) { return g_err; }
+
+int egs_device_props_query(int device, egs_device_props* out) {
+    EGS_ARG(out != nullptr, 2);
+    hipDeviceProp_t p;
+    EGS_HIP(hipGetDeviceProperties(&p, device));
+    out->compute_units = p.multiProcessorCount;
+    out->wavefront_size = p.warpSize;
+    out->lds_bytes_per_block = (int)p.sharedMemPerBlock;
+    out->clock_khz = p.clockRate;
+    out->hbm_bytes = (int64_t)p.totalGlobalMem;
+    strncpy(out->arch, p.gcnArchName, sizeof(out->arch) - 1);
+    out->arch[sizeof(out->arch) - 1] = 0;
+    return 0;
+}
+
+int egs_diag_ssm_lambda(int mode, const double* p0, const double* p1, const double* p2, int64_t n,
+                        double* out_lambda, egs_stream_t stream) {
+    EGS_ARG(mode == EGS_DIAG_LRU || mode == EGS_DIAG_S5_ZOH, 1);
+    EGS_ARG(n >= 0, 5);
+    if (n == 0) return 0;
+    EGS_ARG(p0 != nullptr, 2);
+    EGS_ARG(p1 != nullptr, 3);
+    EGS_ARG(mode == EGS_DIAG_LRU || p2 != nullptr, 4);
+    EGS_ARG(out_lambda != nullptr, 6);
+    return diag_ssm_launch(mode, p0, p1, p2, n, out_lambda, as_stream(stream));
+}
+
+int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const double* p_re, const double* p_im,
+                      const double* log_step, int64_t nmat, int n, double* ab, egs_stream_t stream) {
+    EGS_ARG(nmat >= 0, 6);
+    EGS_ARG(n >= 0 && n <= 2048, 7);
+    if (nmat == 0 || n == 0) return 0;
+    EGS_ARG(lambda_re != nullptr, 1);
+    EGS_ARG(lambda_im != nullptr, 2);
+    EGS_ARG(p_re != nullptr, 3);
+    EGS_ARG(p_im != nullptr, 4);
+    EGS_ARG(log_step != nullptr, 5);
+    EGS_ARG(ab != nullptr, 8);
+    return s4_dplr_launch(lambda_re, lambda_im, p_re, p_im, log_step, nmat, n, ab, as_stream(stream));
+}
+
+size_t egs_eig_workspace_bytes(int dtype, int64_t nmat, int n) {
+    if (nmat <= 0 || n <= 0) return 256;
+    size_t b;
+    if (dtype == EGS_F64 && n <= 64) b = eig_real_lds_workspace_bytes(nmat, n);
+    else b = eig_cplx_workspace_bytes(nmat, n);
+    return b < 256 ? 256 : b;
+}
+
+int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int lda, int64_t stride, double* w,
+                            int32_t* info, void* workspace, size_t workspace_bytes, egs_stream_t stream) {
+    EGS_ARG(dtype == EGS_F64 || dtype == EGS_C128, 2);
+    EGS_ARG(nmat >= 0, 3);
+    EGS_ARG(n >= 0 && n <= 1024, 4);
+    if (nmat == 0 || n == 0) return 0;
+    EGS_ARG(a != nullptr, 1);
+    EGS_ARG(lda >= n, 5);
+    EGS_ARG(stride >= (int64_t)(n - 1) * lda + n || nmat == 1, 6);
+    EGS_ARG(w != nullptr, 7);
+    EGS_ARG(info != nullptr, 8);
+    EGS_ARG(workspace != nullptr, 9);
+    if (dtype == EGS_F64 && n <= 64)
+        return eig_real_lds_launch(static_cast<const double*>(a), nmat, n, lda, stride, w, info, workspace,
+                                   workspace_bytes, as_stream(stream));
+    return eig_cplx_launch(a, dtype == EGS_F64, nmat, n, lda, stride, w, info, workspace, workspace_bytes,
+                           as_stream(stream));
+}
+
+int egs_hessenberg_batched(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h,
+                           egs_stream_t stream) {
+    EGS_ARG(nmat >= 0, 2);
+    EGS_ARG(n >= 0 && n <= 64, 3);
+    if (nmat == 0 || n == 0) return 0;
+    EGS_ARG(a != nullptr, 1);
+    EGS_ARG(lda >= n, 4);
+    EGS_ARG(stride >= (int64_t)(n - 1) * lda + n || nmat == 1, 5);
+    EGS_ARG(h != nullptr, 6);
+    return hess_real_launch(a, nmat, n, lda, stride, h, as_stream(stream));
+}
+
+int egs_hseqr_batched(const double* h, int64_t nmat, int n, double* w, int32_t* info, egs_stream_t stream) {
+    EGS_ARG(nmat >= 0, 2);
+    EGS_ARG(n >= 0 && n <= 64, 3);
+    if (nmat == 0 || n == 0) return 0;
+    EGS_ARG(h != nullptr, 1);
+    EGS_ARG(w != nullptr, 4);
+    EGS_ARG(info != nullptr, 5);
+    return hqr_real_launch(h, nmat, n, w, info, as_stream(stream));
+}
+
+int egs_mamba2_lambda(const float* x, int64_t ntok, int d_model, int64_t ldx, const float* w_dt, const float* b_dt,
+                      const float* dt_bias, const float* a_log, int nheads, float* out, egs_stream_t stream) {
+    EGS_ARG(ntok >= 0, 2);
+    EGS_ARG(d_model > 0, 3);
+    EGS_ARG(ldx >= d_model, 4);
+    EGS_ARG(nheads > 0 && nheads <= 1024, 9);
+    if (ntok == 0) return 0;
+    EGS_ARG(x != nullptr, 1);
+    EGS_ARG(w_dt != nullptr, 5);
+    EGS_ARG(dt_bias != nullptr, 7);
+    EGS_ARG(a_log != nullptr, 8);
+    EGS_ARG(out != nullptr, 10);
+    return mamba2_lambda_launch(x, ntok, d_model, ldx, w_dt, b_dt, dt_bias, a_log, nheads, out, as_stream(stream));
+}
+
+int egs_mamba2_lti_lambda(const float* a_param, const float* beta, int nheads, int64_t ntok, float* out,
+                          egs_stream_t stream) {
+    EGS_ARG(nheads > 0, 3);
+    EGS_ARG(ntok >= 0, 4);
+    if (ntok == 0) return 0;
+    EGS_ARG(a_param != nullptr, 1);
+    EGS_ARG(beta != nullptr, 2);
+    EGS_ARG(out != nullptr, 5);
+    return mamba2_lti_launch(a_param, beta, nheads, ntok, out, as_stream(stream));
+}
+
+size_t egs_attn_workspace_bytes(int64_t batch, int64_t seqlen, int d_qk, int num_heads) {
+    if (batch <= 0 || seqlen <= 0 || d_qk <= 0 || num_heads <= 0) return 256;
+    return attn_workspace_bytes(batch, seqlen, d_qk, num_heads);
+}
+
+static int attn_common(bool softmax, const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_qk,
+                       const float* b_qk, int d_qk, int num_heads, double* eta, void* workspace,
+                       size_t workspace_bytes, egs_stream_t stream) {
+    EGS_ARG(batch >= 0, 2);
+    EGS_ARG(seqlen >= 0, 3);
+    EGS_ARG(d_model > 0, 4);
+    EGS_ARG(d_qk > 0, 7);
+    EGS_ARG(num_heads > 0 && d_qk % num_heads == 0 && num_heads <= 65535, 8);
+    if (batch == 0 || seqlen <= 1) return 0;
+    EGS_ARG(x != nullptr, 1);
+    EGS_ARG(w_qk != nullptr, 5);
+    EGS_ARG(eta != nullptr, 9);
+    EGS_ARG(workspace != nullptr, 10);
+    return attn_eta_launch(softmax, x, batch, seqlen, d_model, w_qk, b_qk, d_qk, num_heads, eta, workspace,
+                           workspace_bytes, as_stream(stream));
+}
+
+int egs_linattn_eta(const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_qk, const float* b_qk,
+                    int d_qk, int num_heads, double* eta, void* workspace, size_t workspace_bytes,
+                    egs_stream_t stream) {
+    return attn_common(false, x, batch, seqlen, d_model, w_qk, b_qk, d_qk, num_heads, eta, workspace, workspace_bytes,
+                       stream);
+}
+
+int egs_softmax_eta(const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_qk, const float* b_qk,
+                    int d_qk, int num_heads, double* eta, void* workspace, size_t workspace_bytes,
+                    egs_stream_t stream) {
+    return attn_common(true, x, batch, seqlen, d_model, w_qk, b_qk, d_qk, num_heads, eta, workspace, workspace_bytes,
+                       stream);
+}
+
+int egs_normattn_eta(const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_n, const float* b_n,
+                     const float* offset, int norm_fn, int num_heads, double* eta, egs_stream_t stream) {
+    EGS_ARG(batch >= 0, 2);
+    EGS_ARG(seqlen >= 0, 3);
+    EGS_ARG(d_model > 0, 4);
+    EGS_ARG(norm_fn >= EGS_NORM_EXP && norm_fn <= EGS_NORM_SIGMOID, 8);
+    EGS_ARG(num_heads > 0 && num_heads <= 1024, 9);
+    if (batch == 0 || seqlen <= 1) return 0;
+    EGS_ARG(x != nullptr, 1);
+    EGS_ARG(w_n != nullptr, 5);
+    EGS_ARG(eta != nullptr, 10);
+    return normattn_eta_launch(x, batch, seqlen, d_model, w_n, b_n, offset, norm_fn, num_heads, eta,
+                               as_stream(stream));
+}
+
+int egs_threshold_hist(const void* vals, int dtype, int transform, int64_t outer, int64_t t_len, int64_t inner,
+                       const double* edges_host, int nedges, double* pct, egs_stream_t stream) {
+    EGS_ARG(dtype >= EGS_F32 && dtype <= EGS_C128, 2);
+    EGS_ARG(transform >= EGS_HIST_VALUE && transform <= EGS_HIST_ZERO, 3);
+    EGS_ARG(!(transform == EGS_HIST_VALUE && (dtype == EGS_C64 || dtype == EGS_C128)), 3);
+    EGS_ARG(outer >= 0 && outer <= 65535, 4);
+    EGS_ARG(t_len >= 0, 5);
+    EGS_ARG(inner >= 0, 6);
+    EGS_ARG(edges_host != nullptr, 7);
+    EGS_ARG(nedges >= 1 && nedges <= 15, 8);
+    if (outer == 0 || inner == 0) return 0;
+    EGS_ARG(vals != nullptr || t_len == 0, 1);
+    EGS_ARG(pct != nullptr, 9);
+    return threshold_hist_launch(vals, dtype, transform, outer, t_len, inner, edges_host, nedges, pct,
+                                 as_stream(stream));
+}
+
+}  // extern "C"

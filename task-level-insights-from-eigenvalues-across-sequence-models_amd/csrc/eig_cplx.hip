@@ -1,0 +1,342 @@
+// K5 (complex, and real n > 64): batched eigenvalues of dense complex128 matrices, ONE WORKGROUP PER MATRIX.
+//
+// This is the generalisation of the reference's only dense eigendecomposition -- np.linalg.eigvals(Ab) on the
+// bilinear-discretised S4 DPLR matrix (analysis/eval_eig.py:296; N = state_dim in {64, 128, 512}) -- from one
+// matrix per layer to (layers x feature columns) matrices.
+//
+//   phase 1: Householder reduction to Hessenberg form (unblocked xGEHD2 order: H <- Hk^H H Hk)
+//   phase 2: single-shift QR with the xLAHQR control flow (Ahues-Tisseur deflation test on |re|+|im|
+//            magnitudes, Wilkinson shift, exceptional shifts every 10 stalled iterations, start at two
+//            consecutive small subdiagonals); 2-element reflectors; eigenvalues only (active window only).
+// The working copy of the matrix lives in LDS when it fits (n <= 96), otherwise in the caller's workspace
+// (L2 / Infinity-Cache resident: 1 MB per 256 x 256 matrix).  Subdiagonals are NOT kept real (LAPACK rescales
+// to keep them real; the general-complex reflector formulas below do not need that).
+#include "egs_common.h"
+
+namespace egs {
+
+struct zc {
+    double re, im;
+};
+__device__ __forceinline__ zc zmk(double r, double i) { return {r, i}; }
+__device__ __forceinline__ zc zadd(zc a, zc b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ zc zsub(zc a, zc b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ zc zmul(zc a, zc b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ zc zmulc(zc a, zc b) {   // a * conj(b)
+    return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im};
+}
+__device__ __forceinline__ zc zscale(zc a, double s) { return {a.re * s, a.im * s}; }
+__device__ __forceinline__ zc zconj(zc a) { return {a.re, -a.im}; }
+__device__ __forceinline__ double zabs1(zc a) { return fabs(a.re) + fabs(a.im); }
+__device__ __forceinline__ double zabs(zc a) { return hypot(a.re, a.im); }
+__device__ __forceinline__ zc zdiv(zc a, zc b) {   // Smith's algorithm (xLADIV spirit)
+    if (fabs(b.re) >= fabs(b.im)) {
+        const double r = b.im / b.re, d = b.re + b.im * r;
+        return {(a.re + a.im * r) / d, (a.im - a.re * r) / d};
+    }
+    const double r = b.re / b.im, d = b.im + b.re * r;
+    return {(a.re * r + a.im) / d, (a.im * r - a.re) / d};
+}
+__device__ __forceinline__ zc zsqrt(zc a) {
+    const double m = zabs(a);
+    if (m == 0.0) return {0.0, 0.0};
+    double sr = sqrt(0.5 * (m + fabs(a.re)));
+    double si = 0.5 * a.im / sr;
+    if (a.re >= 0.0) return {sr, si};
+    return {fabs(si), copysign(sr, a.im)};
+}
+
+constexpr int kCThreads = 256;
+
+// 2-element reflector (xLARFG, n = 2): on return alpha := beta (real), x := v2, tau
+__device__ __forceinline__ void zlarfg2(zc& alpha, zc& x, zc& tau) {
+    const double xnorm = zabs(x);
+    if (xnorm == 0.0 && alpha.im == 0.0) {
+        tau = {0.0, 0.0};
+        return;
+    }
+    const double beta = -copysign(sqrt(alpha.re * alpha.re + alpha.im * alpha.im + xnorm * xnorm), alpha.re);
+    tau = {(beta - alpha.re) / beta, -alpha.im / beta};
+    const zc sc = zdiv({1.0, 0.0}, {alpha.re - beta, alpha.im});
+    x = zmul(x, sc);
+    alpha = {beta, 0.0};
+}
+
+template <typename T>
+__device__ __forceinline__ T block_reduce_sum(T v, T* red) {
+    // red: LDS scratch of kCThreads/64 entries
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    T tot = red[0];
+    for (int w = 1; w < kCThreads / 64; ++w) tot += red[w];
+    return tot;
+}
+
+// INREAL: the input matrices are real fp64 (converted on load).  LDS: working copy in dynamic shared memory.
+template <bool INREAL, bool LDS>
+__global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __restrict__ a, int n, int lda,
+                                                             int64_t stride, double* __restrict__ w,
+                                                             int32_t* __restrict__ info_out,
+                                                             double* __restrict__ work) {
+    extern __shared__ double dyn[];
+    __shared__ double red[kCThreads / 64];
+    __shared__ int s_idx;
+    const int tid = threadIdx.x;
+    const int64_t mat = blockIdx.x;
+    const int ldh = LDS ? (n + 1) : n;
+    zc* H = LDS ? reinterpret_cast<zc*>(dyn) : reinterpret_cast<zc*>(work) + mat * (int64_t)n * n;
+    zc* vsh = LDS ? reinterpret_cast<zc*>(dyn) + (size_t)n * ldh : reinterpret_cast<zc*>(dyn);   // n entries
+#define HM(i, j) H[(int64_t)(i) * ldh + (j)]
+
+    // ---- load ----
+    {
+        const double* src = a + mat * stride * (INREAL ? 1 : 2);
+        for (int idx = tid; idx < n * n; idx += kCThreads) {
+            const int i = idx / n, j = idx - i * n;
+            zc v;
+            if (INREAL) v = {src[(int64_t)i * lda + j], 0.0};
+            else v = {src[2 * ((int64_t)i * lda + j)], src[2 * ((int64_t)i * lda + j) + 1]};
+            HM(i, j) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: Hessenberg reduction ----
+    for (int k = 0; k < n - 2; ++k) {
+        double part = 0.0;
+        for (int i = k + 2 + tid; i < n; i += kCThreads) {
+            const zc x = HM(i, k);
+            part += x.re * x.re + x.im * x.im;
+        }
+        const double xnorm2 = block_reduce_sum(part, red);
+        zc alpha = HM(k + 1, k);
+        if (xnorm2 == 0.0 && alpha.im == 0.0) continue;          // block-uniform
+        const double beta = -copysign(sqrt(alpha.re * alpha.re + alpha.im * alpha.im + xnorm2), alpha.re);
+        const zc tau = {(beta - alpha.re) / beta, -alpha.im / beta};
+        const zc sc = zdiv({1.0, 0.0}, {alpha.re - beta, alpha.im});
+        __syncthreads();                                          // everyone has read alpha
+        for (int i = k + 1 + tid; i < n; i += kCThreads) {
+            if (i == k + 1) {
+                vsh[i] = {1.0, 0.0};
+                HM(i, k) = {beta, 0.0};
+            } else {
+                vsh[i] = zmul(HM(i, k), sc);
+                HM(i, k) = {0.0, 0.0};
+            }
+        }
+        __syncthreads();
+        // right: A(0:n, k+1:n) -= tau (A v) v^H      one wave per row, lanes over columns (coalesced)
+        {
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int i = wv; i < n; i += kCThreads / 64) {
+                zc acc = {0.0, 0.0};
+                for (int j = k + 1 + lane; j < n; j += 64) acc = zadd(acc, zmul(HM(i, j), vsh[j]));
+                acc.re = wave_sum(acc.re);
+                acc.im = wave_sum(acc.im);
+                const zc tw = zmul(tau, acc);
+                for (int j = k + 1 + lane; j < n; j += 64) HM(i, j) = zsub(HM(i, j), zmulc(tw, vsh[j]));
+            }
+        }
+        __syncthreads();
+        // left: A(k+1:n, k+1:n) -= conj(tau) v (v^H A)   thread per column (coalesced across threads)
+        for (int j = k + 1 + tid; j < n; j += kCThreads) {
+            zc acc = {0.0, 0.0};
+            for (int i = k + 1; i < n; ++i) acc = zadd(acc, zmul(zconj(vsh[i]), HM(i, j)));
+            const zc tw = zmul(zconj(tau), acc);
+            for (int i = k + 1; i < n; ++i) HM(i, j) = zsub(HM(i, j), zmul(vsh[i], tw));
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: single-shift QR, eigenvalues only ----
+    const double ulp = 2.220446049250313e-16;
+    const double safmin = 2.2250738585072014e-308;
+    const double smlnum = safmin * ((double)n / ulp);
+    const int itmax = 30 * (n > 10 ? n : 10);
+    const int kexsh = 10;
+    double* wout = w + mat * 2 * (int64_t)n;
+    int info = 0;
+    int i = n - 1;
+    int kdefl = 0;
+    while (i >= 0) {
+        int l = 0;
+        bool converged = false;
+        for (int its = 0; its <= itmax; ++its) {
+            // small-subdiagonal search: highest k in (l, i] passing the test
+            if (tid == 0) s_idx = l;
+            __syncthreads();
+            for (int k = l + 1 + tid; k <= i; k += kCThreads) {
+                bool small = false;
+                const double hkk1 = zabs1(HM(k, k - 1));
+                if (hkk1 <= smlnum) {
+                    small = true;
+                } else {
+                    const zc hkk = HM(k, k), hk1k1 = HM(k - 1, k - 1);
+                    double tst = zabs1(hk1k1) + zabs1(hkk);
+                    if (tst == 0.0) {
+                        if (k - 2 >= 0) tst += zabs1(HM(k - 1, k - 2));
+                        if (k + 1 <= n - 1) tst += zabs1(HM(k + 1, k));
+                    }
+                    if (hkk1 <= ulp * tst) {
+                        const double hk1k = zabs1(HM(k - 1, k));
+                        const double ab = fmax(hkk1, hk1k), ba = fmin(hkk1, hk1k);
+                        const double df = zabs1(zsub(hk1k1, hkk));
+                        const double aa = fmax(zabs1(hkk), df), bb = fmin(zabs1(hkk), df);
+                        const double s = aa + ab;
+                        if (ba * (ab / s) <= fmax(smlnum, ulp * (bb * (aa / s)))) small = true;
+                    }
+                }
+                if (small) atomicMax(&s_idx, k);
+            }
+            __syncthreads();
+            l = s_idx;
+            if (l > 0 && tid == 0) HM(l, l - 1) = {0.0, 0.0};
+            if (l >= i) {
+                converged = true;
+                break;
+            }
+            ++kdefl;
+            // shift (block-uniform, every thread computes it from the same elements)
+            zc t;
+            if (kdefl % (2 * kexsh) == 0) {
+                t = zadd({0.75 * zabs1(HM(i, i - 1)), 0.0}, HM(i, i));
+            } else if (kdefl % kexsh == 0) {
+                t = zadd({0.75 * zabs1(HM(l + 1, l)), 0.0}, HM(l, l));
+            } else {
+                t = HM(i, i);
+                const zc u = zmul(zsqrt(HM(i - 1, i)), zsqrt(HM(i, i - 1)));
+                double s = zabs1(u);
+                if (s != 0.0) {
+                    const zc x = zscale(zsub(HM(i - 1, i - 1), t), 0.5);
+                    const double sx = zabs1(x);
+                    s = fmax(s, sx);
+                    const zc xs = zscale(x, 1.0 / s), us = zscale(u, 1.0 / s);
+                    zc y = zscale(zsqrt(zadd(zmul(xs, xs), zmul(us, us))), s);
+                    if (sx > 0.0) {
+                        const zc xn = zscale(x, 1.0 / sx);
+                        if (xn.re * y.re + xn.im * y.im < 0.0) y = {-y.re, -y.im};
+                    }
+                    t = zsub(t, zmul(u, zdiv(u, zadd(x, y))));
+                }
+            }
+            __syncthreads();      // the H(l,l-1) = 0 store above is ordered before the sweep's accesses
+            // start search: highest m in (l, i-1] whose start vector passes; default m = l
+            if (tid == 0) s_idx = l;
+            __syncthreads();
+            for (int m = l + 1 + tid; m <= i - 1; m += kCThreads) {
+                const zc h11 = HM(m, m), h22 = HM(m + 1, m + 1);
+                zc h11s = zsub(h11, t);
+                const double h21 = zabs1(HM(m + 1, m));
+                const double s = zabs1(h11s) + h21;
+                h11s = zscale(h11s, 1.0 / s);
+                const double h21n = h21 / s;
+                const double h10 = zabs1(HM(m, m - 1));
+                if (h10 * h21n <= ulp * (zabs1(h11s) * (zabs1(h11) + zabs1(h22)))) atomicMax(&s_idx, m);
+            }
+            __syncthreads();
+            const int m = s_idx;
+            zc v0, v1;
+            {
+                zc h11s = zsub(HM(m, m), t);
+                zc h21 = HM(m + 1, m);
+                const double s = zabs1(h11s) + zabs1(h21);
+                v0 = zscale(h11s, 1.0 / s);
+                v1 = zscale(h21, 1.0 / s);
+            }
+            __syncthreads();
+            // single-shift QR sweep
+            for (int k = m; k < i; ++k) {
+                zc a0, a1;
+                if (k > m) {
+                    a0 = HM(k, k - 1);
+                    a1 = HM(k + 1, k - 1);
+                } else {
+                    a0 = v0;
+                    a1 = v1;
+                }
+                zc tau;
+                zlarfg2(a0, a1, tau);           // a0 := beta, a1 := v2
+                const zc v2 = a1;
+                // rows k, k+1, columns k..i:  c <- H^H c,  sum = conj(tau) (a + conj(v2) b)
+                for (int j = k + tid; j <= i; j += kCThreads) {
+                    const zc ra = HM(k, j), rb = HM(k + 1, j);
+                    const zc sum = zmul(zconj(tau), zadd(ra, zmul(zconj(v2), rb)));
+                    HM(k, j) = zsub(ra, sum);
+                    HM(k + 1, j) = zsub(rb, zmul(sum, v2));
+                }
+                __syncthreads();                // also: every thread has read the bulge column by now
+                if (k > m && tid == 0) {
+                    HM(k, k - 1) = a0;
+                    HM(k + 1, k - 1) = {0.0, 0.0};
+                }
+                // columns k, k+1, rows l..min(k+2,i):  r <- r H,  sum = tau (a + b v2)
+                const int rmax = (k + 2 < i) ? k + 2 : i;
+                for (int r = l + tid; r <= rmax; r += kCThreads) {
+                    const zc ca = HM(r, k), cb = HM(r, k + 1);
+                    const zc sum = zmul(tau, zadd(ca, zmul(cb, v2)));
+                    HM(r, k) = zsub(ca, sum);
+                    HM(r, k + 1) = zsub(cb, zmulc(sum, v2));
+                }
+                __syncthreads();
+            }
+        }
+        if (!converged) {
+            info = i + 1;
+            break;
+        }
+        if (tid == 0) {
+            const zc e = HM(i, i);
+            wout[2 * i] = e.re;
+            wout[2 * i + 1] = e.im;
+        }
+        kdefl = 0;
+        i = l - 1;
+        __syncthreads();
+    }
+    if (info != 0) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int j = tid; j < info; j += kCThreads) {
+            wout[2 * j] = qnan;
+            wout[2 * j + 1] = qnan;
+        }
+    }
+    if (tid == 0) info_out[mat] = info;
+#undef HM
+}
+
+constexpr int kCplxLdsMaxN = 96;
+
+size_t eig_cplx_workspace_bytes(int64_t nmat, int n) {
+    if (n <= kCplxLdsMaxN) return 256;
+    return (size_t)nmat * n * n * 2 * sizeof(double);
+}
+
+int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, int64_t stride, double* w,
+                    int32_t* info, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (nmat == 0 || n == 0) return 0;
+    if (n > 1024) {
+        set_error("n = %d exceeds the supported maximum of 1024", n);
+        return -4;
+    }
+    const bool lds = n <= kCplxLdsMaxN;
+    if (!lds && workspace_bytes < eig_cplx_workspace_bytes(nmat, n)) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, eig_cplx_workspace_bytes(nmat, n));
+        return -9;
+    }
+    const size_t dyn = lds ? ((size_t)n * (n + 1) + n) * 2 * sizeof(double) : (size_t)n * 2 * sizeof(double);
+    const double* ap = static_cast<const double*>(a);
+    double* wk = static_cast<double*>(workspace);
+    auto launch = [&](auto kern) -> int {
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nmat), dim3(kCThreads), dyn, stream, ap, n, lda, stride, w, info, wk);
+        EGS_LAUNCH_CHECK();
+        return 0;
+    };
+    if (in_real) return lds ? launch(eig_cplx_kernel<true, true>) : launch(eig_cplx_kernel<true, false>);
+    return lds ? launch(eig_cplx_kernel<false, true>) : launch(eig_cplx_kernel<false, false>);
+}
+
+}  // namespace egs

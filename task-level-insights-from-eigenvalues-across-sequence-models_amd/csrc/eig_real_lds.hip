@@ -1,0 +1,516 @@
+// K5 (real, n <= 64): batched eigenvalues of dense real fp64 matrices, LDS-resident, ONE WAVEFRONT PER
+// MATRIX (lane = column index for row operations, lane = row index for column operations; both access
+// patterns are bank-conflict-free with an odd leading dimension).
+//
+//   hess_real_kernel : Householder reduction to upper-Hessenberg form, global A -> global H workspace
+//   hqr_real_kernel  : Francis double-shift QR on the Hessenberg matrix (LAPACK xLAHQR control flow:
+//                      Ahues-Tisseur deflation test, Wilkinson double shift, exceptional shifts every 10
+//                      stalled iterations, start at two consecutive small subdiagonals), eigenvalues only.
+//
+// Replaces np.linalg.eigvals at analysis/eval_eig.py:296 for real batches (BASELINE config C2).
+// The QR kernel packs TWO Hessenberg matrices into one (n) x (n+7) LDS array -- one stored normally in
+// columns >= row+4, the other transposed in columns <= row+3 -- so 8 matrices fit in 145 KB of a CU's LDS.
+#include "egs_common.h"
+
+namespace egs {
+
+// element (i,j) of the wave's matrix lives at hm[i*sr + j*sc]
+struct MatView {
+    double* hm;
+    int sr, sc;
+    __device__ __forceinline__ double& at(int i, int j) const { return hm[i * sr + j * sc]; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Hessenberg reduction (unblocked, xGEHD2-style), one wave per matrix, full n x ld layout in LDS.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kHessLd = 65;            // odd leading dimension: row and column sweeps conflict-free
+constexpr int kHessWaves = 4;          // matrices per workgroup (4 x 33,280 B = 133 KB LDS)
+
+__global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
+    const double* __restrict__ a, int64_t nmat, int n, int lda, int64_t stride, double* __restrict__ hout) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int64_t mat = (int64_t)blockIdx.x * kHessWaves + wave;
+    if (mat >= nmat) return;                       // whole wave exits; no workgroup barriers are used
+    double* s = smem + (size_t)wave * (kWave * kHessLd);
+    const double* src = a + mat * stride;
+
+    // coalesced load: consecutive lanes read consecutive elements of a row
+    for (int i = 0; i < n; ++i)
+        if (lane < n) s[i * kHessLd + lane] = src[(int64_t)i * lda + lane];
+    wave_lds_sync();
+
+    for (int k = 0; k < n - 2; ++k) {
+        // lane i holds x_i = A(i,k), i > k
+        const bool below = (lane > k) && (lane < n);
+        const double xi = below ? s[lane * kHessLd + k] : 0.0;
+        const double alpha = bcast_lane(xi, k + 1);
+        const double xnorm2 = wave_sum((lane > k + 1) ? xi * xi : 0.0);
+        if (xnorm2 == 0.0) continue;               // wave-uniform: nothing to annihilate
+        const double nrm = sqrt(alpha * alpha + xnorm2);
+        const double beta = -copysign(nrm, alpha);
+        const double tau = (beta - alpha) / beta;
+        const double scal = 1.0 / (alpha - beta);
+        const double v = (lane == k + 1) ? 1.0 : ((lane > k + 1 && lane < n) ? xi * scal : 0.0);
+        if (below) s[lane * kHessLd + k] = (lane == k + 1) ? beta : 0.0;
+
+        // left: A(k+1:, k+1:) -= tau v (v^T A)      lane = column j
+        {
+            const bool act = below;                 // j in k+1..n-1
+            double w = 0.0;
+#pragma unroll 4
+            for (int i = k + 1; i < n; ++i) {
+                const double vi = bcast_lane(v, i);
+                const double aij = act ? s[i * kHessLd + lane] : 0.0;
+                w = fma(vi, aij, w);
+            }
+            w *= tau;
+#pragma unroll 4
+            for (int i = k + 1; i < n; ++i) {
+                const double vi = bcast_lane(v, i);
+                if (act) s[i * kHessLd + lane] = fma(-vi, w, s[i * kHessLd + lane]);
+            }
+        }
+        wave_lds_sync();
+        // right: A(:, k+1:) -= tau (A v) v^T        lane = row i
+        {
+            const bool act = lane < n;
+            double u = 0.0;
+#pragma unroll 4
+            for (int j = k + 1; j < n; ++j) {
+                const double vj = bcast_lane(v, j);
+                const double aij = act ? s[lane * kHessLd + j] : 0.0;
+                u = fma(aij, vj, u);
+            }
+            u *= tau;
+#pragma unroll 4
+            for (int j = k + 1; j < n; ++j) {
+                const double vj = bcast_lane(v, j);
+                if (act) s[lane * kHessLd + j] = fma(-u, vj, s[lane * kHessLd + j]);
+            }
+        }
+        wave_lds_sync();
+    }
+
+    // store the Hessenberg matrix densely (exact zeros below the subdiagonal)
+    double* dst = hout + mat * (int64_t)n * n;
+    for (int i = 0; i < n; ++i)
+        if (lane < n) dst[(int64_t)i * n + lane] = (i > lane + 1) ? 0.0 : s[i * kHessLd + lane];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2x2 standardisation (xLANV2): eigenvalues of [[a,b],[c,d]]
+// ---------------------------------------------------------------------------------------------------
+__device__ inline void lanv2_eig(double a, double b, double c, double d, double& rt1r, double& rt1i,
+                                 double& rt2r, double& rt2i) {
+    const double eps = 2.220446049250313e-16;
+    const double multpl = 4.0;
+    if (c == 0.0) {
+    } else if (b == 0.0) {
+        const double t = d;
+        d = a;
+        a = t;
+        b = -c;
+        c = 0.0;
+    } else if ((a - d) == 0.0 && ((b > 0.0) != (c > 0.0))) {
+    } else {
+        double temp = a - d;
+        double p = 0.5 * temp;
+        const double bcmax = fmax(fabs(b), fabs(c));
+        const double bcmis = fmin(fabs(b), fabs(c)) * copysign(1.0, b) * copysign(1.0, c);
+        const double scale = fmax(fabs(p), bcmax);
+        double z = (p / scale) * p + (bcmax / scale) * bcmis;
+        if (z >= multpl * eps) {
+            z = p + copysign(sqrt(scale) * sqrt(z), p);
+            a = d + z;
+            d = d - (bcmax / z) * bcmis;
+            b = b - c;
+            c = 0.0;
+        } else {
+            const double sigma = b + c;
+            const double tau = hypot(sigma, temp);
+            const double cs = sqrt(0.5 * (1.0 + fabs(sigma) / tau));
+            const double sn = -(p / (tau * cs)) * copysign(1.0, sigma);
+            const double aa = a * cs + b * sn;
+            const double bb = -a * sn + b * cs;
+            const double cc = c * cs + d * sn;
+            const double dd = -c * sn + d * cs;
+            a = aa * cs + cc * sn;
+            b = bb * cs + dd * sn;
+            c = -aa * sn + cc * cs;
+            d = -bb * sn + dd * cs;
+            temp = 0.5 * (a + d);
+            a = temp;
+            d = temp;
+            if (c != 0.0) {
+                if (b != 0.0) {
+                    if ((b > 0.0) == (c > 0.0)) {
+                        const double sab = sqrt(fabs(b));
+                        const double sac = sqrt(fabs(c));
+                        p = copysign(sab * sac, c);
+                        a = temp + p;
+                        d = temp - p;
+                        b = b - c;
+                        c = 0.0;
+                    }
+                } else {
+                    b = -c;
+                    c = 0.0;
+                }
+            }
+        }
+    }
+    rt1r = a;
+    rt2r = d;
+    if (c == 0.0) {
+        rt1i = 0.0;
+        rt2i = 0.0;
+    } else {
+        rt1i = sqrt(fabs(b)) * sqrt(fabs(c));
+        rt2i = -rt1i;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Francis double-shift QR, eigenvalues only, one wave per matrix.  All control flow is wave-uniform: the
+// scalar quantities (shifts, reflectors, deflation decisions) are computed redundantly by every lane from
+// broadcast LDS reads; the O(n) row / column updates of a bulge step are spread over the lanes.
+// ---------------------------------------------------------------------------------------------------
+__device__ void hqr_wave(const MatView H, const int n, const int lane, double* __restrict__ w_out,
+                         int32_t* __restrict__ info_out) {
+    const double ulp = 2.220446049250313e-16;                      // dlamch('P')
+    const double safmin = 2.2250738585072014e-308;
+    const double smlnum = safmin * ((double)n / ulp);
+    const int itmax = 30 * (n > 10 ? n : 10);
+    const int kexsh = 10;
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+
+    int info = 0;
+    int i = n - 1;
+    int kdefl = 0;
+    while (i >= 0) {
+        int l = 0;
+        bool converged = false;
+        for (int its = 0; its <= itmax; ++its) {
+            // ---- look for a single small subdiagonal element: lane k tests H(k,k-1), l < k <= i ----
+            bool small = false;
+            if (lane > l && lane <= i) {
+                const int k = lane;
+                const double hkk1 = fabs(H.at(k, k - 1));
+                if (hkk1 <= smlnum) {
+                    small = true;
+                } else {
+                    const double hkk = H.at(k, k);
+                    const double hk1k1 = H.at(k - 1, k - 1);
+                    double tst = fabs(hk1k1) + fabs(hkk);
+                    if (tst == 0.0) {
+                        if (k - 2 >= 0) tst += fabs(H.at(k - 1, k - 2));
+                        if (k + 1 <= n - 1) tst += fabs(H.at(k + 1, k));
+                    }
+                    if (hkk1 <= ulp * tst) {
+                        const double hk1k = fabs(H.at(k - 1, k));
+                        const double ab = fmax(hkk1, hk1k);
+                        const double ba = fmin(hkk1, hk1k);
+                        const double df = fabs(hk1k1 - hkk);
+                        const double aa = fmax(fabs(hkk), df);
+                        const double bb = fmin(fabs(hkk), df);
+                        const double s = aa + ab;
+                        if (ba * (ab / s) <= fmax(smlnum, ulp * (bb * (aa / s)))) small = true;
+                    }
+                }
+            }
+            const unsigned long long smask = __ballot(small);
+            l = smask ? (63 - __builtin_clzll(smask)) : l;
+            l = uniform(l);
+            if (l > 0 && lane == 0) H.at(l, l - 1) = 0.0;
+            if (l >= i - 1) {
+                converged = true;
+                break;
+            }
+            wave_lds_sync();
+            ++kdefl;
+
+            // ---- shifts (uniform) ----
+            double h11, h21, h12, h22;
+            if (kdefl % (2 * kexsh) == 0) {
+                const double s = fabs(H.at(i, i - 1)) + fabs(H.at(i - 1, i - 2));
+                h11 = 0.75 * s + H.at(i, i);
+                h12 = -0.4375 * s;
+                h21 = s;
+                h22 = h11;
+            } else if (kdefl % kexsh == 0) {
+                const double s = fabs(H.at(l + 1, l)) + fabs(H.at(l + 2, l + 1));
+                h11 = 0.75 * s + H.at(l, l);
+                h12 = -0.4375 * s;
+                h21 = s;
+                h22 = h11;
+            } else {
+                h11 = H.at(i - 1, i - 1);
+                h21 = H.at(i, i - 1);
+                h12 = H.at(i - 1, i);
+                h22 = H.at(i, i);
+            }
+            double rt1r, rt1i, rt2r, rt2i;
+            {
+                const double s = fabs(h11) + fabs(h12) + fabs(h21) + fabs(h22);
+                if (s == 0.0) {
+                    rt1r = rt1i = rt2r = rt2i = 0.0;
+                } else {
+                    h11 /= s;
+                    h21 /= s;
+                    h12 /= s;
+                    h22 /= s;
+                    const double tr = (h11 + h22) * 0.5;
+                    const double det = (h11 - tr) * (h22 - tr) - h12 * h21;
+                    const double rtdisc = sqrt(fabs(det));
+                    if (det >= 0.0) {
+                        rt1r = tr * s;
+                        rt2r = rt1r;
+                        rt1i = rtdisc * s;
+                        rt2i = -rt1i;
+                    } else {
+                        rt1r = tr + rtdisc;
+                        rt2r = tr - rtdisc;
+                        if (fabs(rt1r - h22) <= fabs(rt2r - h22)) {
+                            rt1r = rt1r * s;
+                            rt2r = rt1r;
+                        } else {
+                            rt2r = rt2r * s;
+                            rt1r = rt2r;
+                        }
+                        rt1i = 0.0;
+                        rt2i = 0.0;
+                    }
+                }
+            }
+
+            // ---- two consecutive small subdiagonals: lane m evaluates the start vector at row m ----
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+            bool start_ok = false;
+            if (lane >= l && lane <= i - 2) {
+                const int mm = lane;
+                const double hmm = H.at(mm, mm);
+                const double hm1m = H.at(mm + 1, mm);
+                const double hm1m1 = H.at(mm + 1, mm + 1);
+                double s = fabs(hmm - rt2r) + fabs(rt2i) + fabs(hm1m);
+                const double h21s = hm1m / s;
+                v0 = h21s * H.at(mm, mm + 1) + (hmm - rt1r) * ((hmm - rt2r) / s) - rt1i * (rt2i / s);
+                v1 = h21s * (hmm + hm1m1 - rt1r - rt2r);
+                v2 = h21s * H.at(mm + 2, mm + 1);
+                s = fabs(v0) + fabs(v1) + fabs(v2);
+                v0 /= s;
+                v1 /= s;
+                v2 /= s;
+                if (mm == l) {
+                    start_ok = true;
+                } else {
+                    const double h00 = fabs(H.at(mm - 1, mm - 1));
+                    start_ok = fabs(H.at(mm, mm - 1)) * (fabs(v1) + fabs(v2)) <=
+                               ulp * fabs(v0) * (h00 + fabs(hmm) + fabs(hm1m1));
+                }
+            }
+            const unsigned long long mmask = __ballot(start_ok);      // bit l is always set
+            const int m = uniform(63 - __builtin_clzll(mmask));
+            v0 = bcast_lane(v0, m);
+            v1 = bcast_lane(v1, m);
+            v2 = bcast_lane(v2, m);
+
+            // ---- double-shift QR sweep: chase the bulge from row m to row i ----
+            for (int k = m; k < i; ++k) {
+                const bool three = (k < i - 1);                       // reflector order 3 (else 2)
+                double a0, a1, a2;
+                if (k > m) {
+                    a0 = H.at(k, k - 1);
+                    a1 = H.at(k + 1, k - 1);
+                    a2 = three ? H.at(k + 2, k - 1) : 0.0;
+                } else {
+                    a0 = v0;
+                    a1 = v1;
+                    a2 = v2;                                          // k == m implies three
+                }
+                // xLARFG on (a0; a1, a2)
+                const double xs = a1 * a1 + a2 * a2;
+                double t1 = 0.0, beta = a0, u1 = 0.0, u2 = 0.0;
+                if (xs != 0.0) {
+                    const double nrm2 = fma(a0, a0, xs);
+                    const double rn = fast_rsqrt(nrm2);               // 1/||a||
+                    const double nrm = nrm2 * rn;
+                    beta = -copysign(nrm, a0);
+                    const double apn = fabs(a0) + nrm;                // |a0 - beta|
+                    t1 = apn * rn;                                    // (beta - a0)/beta
+                    const double scal = copysign(fast_rcp(apn), a0);  // 1/(a0 - beta)
+                    u1 = a1 * scal;
+                    u2 = a2 * scal;
+                }
+                if (k > m) {
+                    if (lane < (three ? 3 : 2)) H.at(k + lane, k - 1) = (lane == 0) ? beta : 0.0;
+                } else if (m > l) {
+                    if (lane == 0) H.at(k, k - 1) = H.at(k, k - 1) * (1.0 - t1);
+                }
+                const double t2 = t1 * u1;
+                const double t3 = t1 * u2;
+                // row operation on rows k..k+2, columns k..i       (lane = column)
+                if (lane >= k && lane <= i) {
+                    const double r0 = H.at(k, lane);
+                    const double r1 = H.at(k + 1, lane);
+                    const double r2 = three ? H.at(k + 2, lane) : 0.0;
+                    const double sum = fma(u2, r2, fma(u1, r1, r0));
+                    H.at(k, lane) = fma(-sum, t1, r0);
+                    H.at(k + 1, lane) = fma(-sum, t2, r1);
+                    if (three) H.at(k + 2, lane) = fma(-sum, t3, r2);
+                }
+                wave_lds_sync();
+                // column operation on columns k..k+2, rows l..min(k+3,i)   (lane = row)
+                const int rmax = three ? ((k + 3 < i) ? k + 3 : i) : i;
+                if (lane >= l && lane <= rmax) {
+                    const double c0 = H.at(lane, k);
+                    const double c1 = H.at(lane, k + 1);
+                    const double c2 = three ? H.at(lane, k + 2) : 0.0;
+                    const double sum = fma(u2, c2, fma(u1, c1, c0));
+                    H.at(lane, k) = fma(-sum, t1, c0);
+                    H.at(lane, k + 1) = fma(-sum, t2, c1);
+                    if (three) H.at(lane, k + 2) = fma(-sum, t3, c2);
+                }
+                wave_lds_sync();
+            }
+        }
+        if (!converged) {
+            info = i + 1;
+            break;
+        }
+        if (l == i) {
+            const double wr = H.at(i, i);
+            if (lane == 0) {
+                w_out[2 * i] = wr;
+                w_out[2 * i + 1] = 0.0;
+            }
+        } else {   // l == i-1: a 2x2 block
+            double rt1r, rt1i, rt2r, rt2i;
+            lanv2_eig(H.at(i - 1, i - 1), H.at(i - 1, i), H.at(i, i - 1), H.at(i, i), rt1r, rt1i, rt2r, rt2i);
+            if (lane == 0) {
+                w_out[2 * (i - 1)] = rt1r;
+                w_out[2 * (i - 1) + 1] = rt1i;
+                w_out[2 * i] = rt2r;
+                w_out[2 * i + 1] = rt2i;
+            }
+        }
+        kdefl = 0;
+        i = l - 1;
+        wave_lds_sync();
+    }
+    if (info != 0) {   // eigenvalues 0..info-1 did not converge
+        for (int j = lane; j < info; j += kWave) {
+            w_out[2 * j] = qnan;
+            w_out[2 * j + 1] = qnan;
+        }
+    }
+    if (lane == 0) *info_out = info;
+}
+
+// Packed-pair LDS layout of the QR kernel: array of n rows x ldp columns per pair.
+//   role 0: H(i,j) at row i, column j+7   (occupied: column >= row+4, since i <= j+3 during a chase)
+//   role 1: H(i,j) at row j, column i     (occupied: column <= row+3)
+__host__ __device__ inline int hqr_pair_ld(int n) {
+    int ld = n + 7;
+    return (ld & 1) ? ld : ld + 1;
+}
+
+__global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
+                                                       double* __restrict__ w, int32_t* __restrict__ info,
+                                                       int waves_per_block) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int64_t mat = (int64_t)blockIdx.x * waves_per_block + wave;
+    if (mat >= nmat) return;
+    const int ldp = hqr_pair_ld(n);
+    double* base = smem + (size_t)(wave >> 1) * ((size_t)n * ldp);
+    MatView H;
+    if ((wave & 1) == 0) {
+        H.hm = base + 7;
+        H.sr = ldp;
+        H.sc = 1;
+    } else {
+        H.hm = base;
+        H.sr = 1;
+        H.sc = ldp;
+    }
+    // load the Hessenberg part plus the three sub-diagonals a bulge may touch (zeros)
+    const double* src = hin + mat * (int64_t)n * n;
+    for (int i = 0; i < n; ++i) {
+        if (lane < n && i <= lane + 3) H.at(i, lane) = (i <= lane + 1) ? src[(int64_t)i * n + lane] : 0.0;
+    }
+    wave_lds_sync();
+    hqr_wave(H, n, lane, w + mat * 2 * (int64_t)n, info + mat);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side launcher
+// ---------------------------------------------------------------------------------------------------
+size_t eig_real_lds_workspace_bytes(int64_t nmat, int n) {
+    const int64_t chunk = nmat < 16384 ? nmat : 16384;
+    return (size_t)chunk * n * n * sizeof(double);
+}
+
+static int set_lds_attrs() {
+    EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hess_real_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hqr_real_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
+int hess_real_launch(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h, hipStream_t stream) {
+    if (nmat == 0 || n == 0) return 0;
+    int st = set_lds_attrs();
+    if (st) return st;
+    const size_t hess_lds = (size_t)kHessWaves * kWave * kHessLd * sizeof(double);
+    const unsigned gh = (unsigned)((nmat + kHessWaves - 1) / kHessWaves);
+    hipLaunchKernelGGL(hess_real_kernel, dim3(gh), dim3(kHessWaves * kWave), hess_lds, stream, a, nmat, n, lda, stride,
+                       h);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
+int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* info, hipStream_t stream) {
+    if (nmat == 0 || n == 0) return 0;
+    int st = set_lds_attrs();
+    if (st) return st;
+    const int ldp = hqr_pair_ld(n);
+    const size_t pair_bytes = (size_t)n * ldp * sizeof(double);
+    int pairs = (int)((160 * 1024) / pair_bytes);
+    if (pairs > 4) pairs = 4;
+    if (pairs < 1) pairs = 1;
+    const int hqr_waves = 2 * pairs;
+    const size_t hqr_lds = pairs * pair_bytes;
+    const unsigned gq = (unsigned)((nmat + hqr_waves - 1) / hqr_waves);
+    hipLaunchKernelGGL(hqr_real_kernel, dim3(gq), dim3(hqr_waves * kWave), hqr_lds, stream, h, nmat, n, w, info,
+                       hqr_waves);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
+int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* w, int32_t* info,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (nmat == 0 || n == 0) return 0;
+    const size_t per_mat = (size_t)n * n * sizeof(double);
+    int64_t chunk = (int64_t)(workspace_bytes / per_mat);
+    if (chunk > nmat) chunk = nmat;
+    if (chunk < 1) {
+        set_error("workspace too small: %zu bytes, need at least %zu", workspace_bytes, per_mat);
+        return -9;
+    }
+    double* hws = static_cast<double*>(workspace);
+    for (int64_t m0 = 0; m0 < nmat; m0 += chunk) {
+        const int64_t cnt = (nmat - m0 < chunk) ? (nmat - m0) : chunk;
+        int st = hess_real_launch(a + m0 * stride, cnt, n, lda, stride, hws, stream);
+        if (st) return st;
+        st = hqr_real_launch(hws, cnt, n, w + m0 * 2 * (int64_t)n, info + m0, stream);
+        if (st) return st;
+    }
+    return 0;
+}
+
+}  // namespace egs

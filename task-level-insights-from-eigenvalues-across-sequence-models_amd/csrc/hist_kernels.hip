@@ -1,0 +1,153 @@
+// a9/a10: radius / phase transforms fused with the 7-bin inclusive-edge threshold histograms of
+// analysis/eval_eig.py:335-391 (quirk Q12), so that only (nbins, outer, inner) percentages leave the GPU
+// instead of the full spectra.
+//
+// vals is [outer, T, inner]; one count per (bin, outer, inner).  Counting is integer work: per-thread
+// register counters, one 64-bit global atomic per (thread, bin) at the end, then a finalize pass that turns
+// the counts into `count / T * 100` with the same two IEEE operations NumPy performs -- bit-exact.
+#include "egs_common.h"
+
+namespace egs {
+
+constexpr int kMaxEdges = 15;
+struct HistEdges {
+    double e[kMaxEdges];
+    int n;
+};
+
+template <int DTYPE>
+__device__ __forceinline__ double load_transformed(const void* vals, int64_t idx, int transform) {
+    double re, im = 0.0;
+    if constexpr (DTYPE == EGS_F32) {
+        re = (double)static_cast<const float*>(vals)[idx];
+    } else if constexpr (DTYPE == EGS_F64) {
+        re = static_cast<const double*>(vals)[idx];
+    } else if constexpr (DTYPE == EGS_C64) {
+        const float2 v = static_cast<const float2*>(vals)[idx];
+        if (transform == EGS_HIST_RADIUS) {            // float32 arithmetic like NumPy on complex64
+            const float r2 = __fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y));
+            return (double)__fsqrt_rn(r2);
+        }
+        if (transform == EGS_HIST_PHASE_DEG) {
+            const float ph = atan2f(v.y, v.x);
+            return (double)__fdiv_rn(__fmul_rn(ph, 180.0f), 3.14159274101257324f);
+        }
+        re = (double)v.x;
+        im = (double)v.y;
+    } else {
+        const double2 v = static_cast<const double2*>(vals)[idx];
+        re = v.x;
+        im = v.y;
+    }
+    switch (transform) {
+        case EGS_HIST_RADIUS:       // sqrt(re^2 + im^2), no FMA contraction (eval_eig.py:605, :726)
+            return __dsqrt_rn(__dadd_rn(__dmul_rn(re, re), __dmul_rn(im, im)));
+        case EGS_HIST_PHASE_DEG:    // atan2(im, re) * 180 / pi (eval_eig.py:614, :734)
+            return __ddiv_rn(__dmul_rn(atan2(im, re), 180.0), 3.141592653589793);
+        case EGS_HIST_ZERO:         // 0 * value (quirk Q13): NaN / inf stay NaN
+            return __dmul_rn(0.0, re);
+        default:
+            return re;
+    }
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(256) void hist_count_kernel(const void* __restrict__ vals, int transform, int64_t outer,
+                                                         int64_t t_len, int64_t inner, HistEdges ed, int rows_per_block,
+                                                         unsigned long long* __restrict__ counts) {
+    // block (x = T-slab, y = outer).  Threads cover `inner` contiguously; a thread's column is fixed, so its
+    // bin counters live in registers.
+    const int64_t o = blockIdx.y;
+    const int tpc = (inner >= 256) ? 1 : (int)(256 / inner);       // rows handled concurrently
+    const int nthreads_used = (inner >= 256) ? 256 : (int)(tpc * inner);
+    if ((int)threadIdx.x >= nthreads_used) return;
+    const int64_t t_begin = (int64_t)blockIdx.x * rows_per_block;
+    int64_t t_end = t_begin + rows_per_block;
+    if (t_end > t_len) t_end = t_len;
+    const int nb = ed.n + 1;
+    for (int64_t c0 = 0; c0 < inner; c0 += 256) {                  // one pass unless inner > 256
+        int64_t c;
+        int r0, rstep;
+        if (inner >= 256) {
+            c = c0 + threadIdx.x;
+            r0 = 0;
+            rstep = 1;
+            if (c >= inner) continue;
+        } else {
+            c = threadIdx.x % inner;
+            r0 = (int)(threadIdx.x / inner);
+            rstep = tpc;
+        }
+        unsigned cnt[kMaxEdges + 1];
+#pragma unroll
+        for (int b = 0; b <= kMaxEdges; ++b) cnt[b] = 0;
+        for (int64_t t = t_begin + r0; t < t_end; t += rstep) {
+            const double v = load_transformed<DTYPE>(vals, (o * t_len + t) * inner + c, transform);
+#pragma unroll
+            for (int b = 0; b <= kMaxEdges; ++b) {
+                if (b < nb) {
+                    bool in;
+                    if (b == 0) in = (v >= 0.0) && (v <= ed.e[0]);
+                    else if (b == nb - 1) in = v > ed.e[b - 1];
+                    else in = (v >= ed.e[b - 1]) && (v <= ed.e[b]);
+                    cnt[b] += in ? 1u : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b <= kMaxEdges; ++b)
+            if (b < nb && cnt[b]) atomicAdd(&counts[((int64_t)b * outer + o) * inner + c], (unsigned long long)cnt[b]);
+        if (inner < 256) break;
+    }
+}
+
+__global__ void hist_finalize_kernel(double* __restrict__ pct, int64_t n, int64_t t_len) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long c = reinterpret_cast<const unsigned long long*>(pct)[i];
+    pct[i] = __dmul_rn(__ddiv_rn((double)c, (double)t_len), 100.0);   // count / T * 100
+}
+
+int threshold_hist_launch(const void* vals, int dtype, int transform, int64_t outer, int64_t t_len, int64_t inner,
+                          const double* edges_host, int nedges, double* pct, hipStream_t stream) {
+    const int64_t nout = (int64_t)(nedges + 1) * outer * inner;
+    if (nout == 0) return 0;
+    EGS_HIP(hipMemsetAsync(pct, 0, (size_t)nout * sizeof(double), stream));
+    if (t_len > 0) {
+        HistEdges ed;
+        ed.n = nedges;
+        for (int i = 0; i < kMaxEdges; ++i) ed.e[i] = (i < nedges) ? edges_host[i] : 0.0;
+        // enough T-slabs to fill the chip even when outer is small
+        int64_t slabs = (2048 + outer - 1) / outer;
+        int64_t rows = (t_len + slabs - 1) / slabs;
+        if (rows < 64) rows = 64;
+        slabs = (t_len + rows - 1) / rows;
+        const dim3 grid((unsigned)slabs, (unsigned)outer);
+        auto* counts = reinterpret_cast<unsigned long long*>(pct);
+        switch (dtype) {
+            case EGS_F32:
+                hipLaunchKernelGGL(hist_count_kernel<EGS_F32>, grid, dim3(256), 0, stream, vals, transform, outer, t_len,
+                                   inner, ed, (int)rows, counts);
+                break;
+            case EGS_F64:
+                hipLaunchKernelGGL(hist_count_kernel<EGS_F64>, grid, dim3(256), 0, stream, vals, transform, outer, t_len,
+                                   inner, ed, (int)rows, counts);
+                break;
+            case EGS_C64:
+                hipLaunchKernelGGL(hist_count_kernel<EGS_C64>, grid, dim3(256), 0, stream, vals, transform, outer, t_len,
+                                   inner, ed, (int)rows, counts);
+                break;
+            default:
+                hipLaunchKernelGGL(hist_count_kernel<EGS_C128>, grid, dim3(256), 0, stream, vals, transform, outer, t_len,
+                                   inner, ed, (int)rows, counts);
+                break;
+        }
+        EGS_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(hist_finalize_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, stream, pct, nout,
+                       t_len);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace egs

@@ -1,0 +1,239 @@
+"""Device ops of the eigenvalue-analysis path: torch tensors in, torch tensors out, compute in HIP.
+
+torch is plumbing only (device memory, current stream); every function calls one entry point of the C ABI
+(include/eigspec.h) on torch's current stream and returns without synchronising.  Nothing here falls back to
+torch / NumPy arithmetic: without a GPU or without libeigspec_hip.so the ops raise.
+"""
+import ctypes
+
+import torch
+
+from . import _capi
+from ._capi import check, lib
+
+_workspaces = {}
+
+
+def _require_cuda(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _capi.EigspecError(f"{name} must be a torch tensor on the GPU (got {type(t).__name__}"
+                                 f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}); "
+                                 "the eigenvalue-analysis path has no CPU fallback")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _workspace(device, nbytes):
+    """Grow-only scratch buffer per device (the C ABI never allocates)."""
+    nbytes = max(int(nbytes), 256)
+    key = (device.type, device.index)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _workspaces[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return buf
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+def device_props(device=0):
+    p = _capi.DeviceProps()
+    check(lib().egs_device_props_query(int(device), ctypes.byref(p)), "egs_device_props_query")
+    return {"compute_units": p.compute_units, "wavefront_size": p.wavefront_size,
+            "lds_bytes_per_block": p.lds_bytes_per_block, "clock_khz": p.clock_khz, "hbm_bytes": p.hbm_bytes,
+            "arch": p.arch.decode()}
+
+
+# ---- K5 -------------------------------------------------------------------------------------------------
+def eig_general_batched(a, workspace=None):
+    """Eigenvalues of a batch of dense matrices a[..., n, n] (float64 or complex128, row-major).
+
+    Returns (w complex128 [..., n], info int32 [...]).  Replaces np.linalg.eigvals (analysis/eval_eig.py:296)."""
+    _require_cuda(a, "a")
+    if a.dtype not in (torch.float64, torch.complex128):
+        raise TypeError(f"eig_general_batched computes in fp64: got {a.dtype}")
+    if a.dim() < 2 or a.shape[-1] != a.shape[-2]:
+        raise ValueError(f"expected [..., n, n], got {tuple(a.shape)}")
+    n = a.shape[-1]
+    batch_shape = a.shape[:-2]
+    a3 = a.reshape(-1, n, n)
+    if not a3.is_contiguous():
+        a3 = a3.contiguous()
+    nmat = a3.shape[0]
+    dtype = _capi.EGS_F64 if a.dtype == torch.float64 else _capi.EGS_C128
+    w = torch.empty((nmat, n), dtype=torch.complex128, device=a.device)
+    info = torch.empty((nmat,), dtype=torch.int32, device=a.device)
+    need = lib().egs_eig_workspace_bytes(dtype, nmat, n)
+    ws = workspace if workspace is not None else _workspace(a.device, need)
+    with torch.cuda.device(a.device):
+        check(lib().egs_eig_general_batched(_ptr(a3), dtype, nmat, n, n, n * n, _ptr(w), _ptr(info), _ptr(ws),
+                                            ws.numel() * ws.element_size(), _stream()), "egs_eig_general_batched")
+    return w.reshape(*batch_shape, n), info.reshape(batch_shape)
+
+
+def hessenberg_batched(a):
+    """Stage 1 of the real LDS solver (n <= 64): a [nmat, n, n] float64 -> Hessenberg h [nmat, n, n]."""
+    _require_cuda(a, "a")
+    a = a.contiguous()
+    nmat, n, _ = a.shape
+    h = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        check(lib().egs_hessenberg_batched(_ptr(a), nmat, n, n, n * n, _ptr(h), _stream()), "egs_hessenberg_batched")
+    return h
+
+
+def hseqr_batched(h):
+    """Stage 2 of the real LDS solver: Hessenberg h [nmat, n, n] float64 -> (w complex128 [nmat, n], info)."""
+    _require_cuda(h, "h")
+    h = h.contiguous()
+    nmat, n, _ = h.shape
+    w = torch.empty((nmat, n), dtype=torch.complex128, device=h.device)
+    info = torch.empty((nmat,), dtype=torch.int32, device=h.device)
+    with torch.cuda.device(h.device):
+        check(lib().egs_hseqr_batched(_ptr(h), nmat, n, _ptr(w), _ptr(info), _stream()), "egs_hseqr_batched")
+    return w, info
+
+
+# ---- K1 / S4 build ----------------------------------------------------------------------------------------
+def diag_ssm_lambda(mode, p0, p1, p2=None):
+    """LRU (mode 'lru': nu_log, theta_log) / S5 (mode 's5': Lambda_re, Lambda_im, log_step) closed forms."""
+    _require_cuda(p0, "p0")
+    m = {"lru": _capi.EGS_DIAG_LRU, "s5": _capi.EGS_DIAG_S5_ZOH}[mode]
+    p0 = p0.to(torch.float64).contiguous().reshape(-1)
+    p1 = p1.to(torch.float64).contiguous().reshape(-1)
+    p2 = p2.to(torch.float64).contiguous().reshape(-1) if p2 is not None else None
+    n = p0.numel()
+    out = torch.empty((n,), dtype=torch.complex128, device=p0.device)
+    with torch.cuda.device(p0.device):
+        check(lib().egs_diag_ssm_lambda(m, _ptr(p0), _ptr(p1), _ptr(p2), n, _ptr(out), _stream()),
+              "egs_diag_ssm_lambda")
+    return out
+
+
+def s4_dplr_build(lambda_re, lambda_im, p, log_step):
+    """Ab [nmat, n, n] complex128 of the bilinear-discretised DPLR SSM (Q = P), for nmat feature columns.
+
+    lambda_re, lambda_im: [nmat, n] real; p: [nmat, n] complex (or real); log_step: [nmat]."""
+    _require_cuda(lambda_re, "lambda_re")
+    lr = lambda_re.to(torch.float64).contiguous()
+    li = lambda_im.to(torch.float64).contiguous()
+    pc = p.to(torch.complex128)
+    pr = pc.real.contiguous()
+    pi = pc.imag.contiguous()
+    ls = log_step.to(torch.float64).contiguous().reshape(-1)
+    nmat, n = lr.shape
+    ab = torch.empty((nmat, n, n), dtype=torch.complex128, device=lr.device)
+    with torch.cuda.device(lr.device):
+        check(lib().egs_s4_dplr_build(_ptr(lr), _ptr(li), _ptr(pr), _ptr(pi), _ptr(ls), nmat, n, _ptr(ab), _stream()),
+              "egs_s4_dplr_build")
+    return ab
+
+
+# ---- K2 -------------------------------------------------------------------------------------------------
+def mamba2_lambda(x, w_dt, b_dt, dt_bias, a_log):
+    """x [B, L, D] fp32 -> lambda [B, L, nheads] fp32 (analysis/eval_eig.py:176-190)."""
+    _require_cuda(x, "x")
+    x = x.to(torch.float32).contiguous()
+    bsz, seqlen, d = x.shape
+    w = w_dt.to(torch.float32).contiguous()
+    nh = w.shape[0]
+    b = b_dt.to(torch.float32).contiguous() if b_dt is not None else None
+    dtb = dt_bias.to(torch.float32).contiguous()
+    al = a_log.to(torch.float32).contiguous()
+    out = torch.empty((bsz, seqlen, nh), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().egs_mamba2_lambda(_ptr(x), bsz * seqlen, d, d, _ptr(w), _ptr(b), _ptr(dtb), _ptr(al), nh,
+                                      _ptr(out), _stream()), "egs_mamba2_lambda")
+    return out
+
+
+def mamba2_lti_lambda(a_param, beta, batch, seqlen):
+    _require_cuda(a_param, "a_param")
+    a = a_param.to(torch.float32).contiguous()
+    bt = beta.to(torch.float32).contiguous().to(a.device)
+    nh = a.numel()
+    out = torch.empty((batch, seqlen, nh), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().egs_mamba2_lti_lambda(_ptr(a), _ptr(bt), nh, batch * seqlen, _ptr(out), _stream()),
+              "egs_mamba2_lti_lambda")
+    return out
+
+
+# ---- K3 / K4 / norm -----------------------------------------------------------------------------------------
+def _attn(fn_name, x, w_qk, b_qk, d_qk, num_heads):
+    _require_cuda(x, "x")
+    x = x.to(torch.float32).contiguous()
+    bsz, seqlen, d = x.shape
+    w = w_qk.to(torch.float32).contiguous()
+    if w.shape != (2 * d_qk, d):
+        raise ValueError(f"w_qk must be [2*d_qk, D] = {(2 * d_qk, d)}, got {tuple(w.shape)}")
+    b = b_qk.to(torch.float32).contiguous() if b_qk is not None else None
+    eta = torch.empty((bsz, max(seqlen - 1, 0), num_heads), dtype=torch.float64, device=x.device)
+    need = lib().egs_attn_workspace_bytes(bsz, seqlen, d_qk, num_heads)
+    ws = _workspace(x.device, need)
+    with torch.cuda.device(x.device):
+        check(getattr(lib(), fn_name)(_ptr(x), bsz, seqlen, d, _ptr(w), _ptr(b), d_qk, num_heads, _ptr(eta), _ptr(ws),
+                                      ws.numel(), _stream()), fn_name)
+    return eta
+
+
+def linattn_eta(x, w_qk, b_qk, d_qk, num_heads):
+    """eta [B, L-1, H] float64 of linear attention (analysis/eval_eig.py:97-135), O(L) streaming form."""
+    return _attn("egs_linattn_eta", x, w_qk, b_qk, d_qk, num_heads)
+
+
+def softmax_eta(x, w_qk, b_qk, d_qk, num_heads):
+    """eta [B, L-1, H] float64 of softmax attention (analysis/eval_eig.py:43-95), no (B,L,L,H) tensor."""
+    return _attn("egs_softmax_eta", x, w_qk, b_qk, d_qk, num_heads)
+
+
+def normattn_eta(x, w_n, b_n, offset, norm_fn, num_heads):
+    """eta [B, L-1, H] float64 of normalised attention (analysis/eval_eig.py:137-174)."""
+    _require_cuda(x, "x")
+    if norm_fn not in _capi.EGS_NORM:
+        raise RuntimeError("normalization function {0} not implemented!".format(norm_fn))   # eval_eig.py:151
+    x = x.to(torch.float32).contiguous()
+    bsz, seqlen, d = x.shape
+    w = w_n.to(torch.float32).contiguous()
+    b = b_n.to(torch.float32).contiguous() if b_n is not None else None
+    off = offset.to(torch.float32).contiguous().to(x.device) if offset is not None else None
+    eta = torch.empty((bsz, max(seqlen - 1, 0), num_heads), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().egs_normattn_eta(_ptr(x), bsz, seqlen, d, _ptr(w), _ptr(b), _ptr(off), _capi.EGS_NORM[norm_fn],
+                                     num_heads, _ptr(eta), _stream()), "egs_normattn_eta")
+    return eta
+
+
+# ---- a9 / a10 ------------------------------------------------------------------------------------------------
+_TRANSFORMS = {"value": _capi.EGS_HIST_VALUE, "radius": _capi.EGS_HIST_RADIUS, "phase": _capi.EGS_HIST_PHASE_DEG,
+               "zero": _capi.EGS_HIST_ZERO}
+_DTYPES = {torch.float32: _capi.EGS_F32, torch.float64: _capi.EGS_F64, torch.complex64: _capi.EGS_C64,
+           torch.complex128: _capi.EGS_C128}
+
+
+def threshold_hist(vals, edges, transform="value"):
+    """Inclusive-edge percentages over axis 1 of vals [outer, T, *inner] -> float64 [len(edges)+1, outer, *inner]
+    (analysis/eval_eig.py:335-391 with the radius / phase transforms of :605-615 / :726-735 fused in)."""
+    _require_cuda(vals, "vals")
+    if vals.dtype not in _DTYPES:
+        raise TypeError(f"unsupported dtype {vals.dtype}")
+    vals = vals.contiguous()
+    outer, t_len = vals.shape[0], vals.shape[1]
+    inner_shape = tuple(vals.shape[2:])
+    inner = 1
+    for s in inner_shape:
+        inner *= s
+    edges = [float(e) for e in edges]
+    c_edges = (ctypes.c_double * len(edges))(*edges)
+    pct = torch.empty((len(edges) + 1, outer) + inner_shape, dtype=torch.float64, device=vals.device)
+    with torch.cuda.device(vals.device):
+        check(lib().egs_threshold_hist(_ptr(vals), _DTYPES[vals.dtype], _TRANSFORMS[transform], outer, t_len, inner,
+                                       c_edges, len(edges), _ptr(pct), _stream()), "egs_threshold_hist")
+    return pct
