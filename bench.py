@@ -41,7 +41,7 @@ def gen_known_spectrum(cnt, n, gen, device):
     lo, hi = np.log(1e-3), np.log(1e-1)
     dt = torch.exp(torch.rand((cnt, npair), generator=gen, device=device, dtype=torch.float64) * (hi - lo) + lo)
     lam = torch.exp(torch.complex(-0.5 * dt, om * dt))
-    a = torch.randn((cnt, n, n), generator=gen, device=device, dtype=torch.float64).triu_(2) * (0.3 / np.sqrt(n))
+    a = torch.randn((cnt, n, n), generator=gen, device=device, dtype=torch.float64).triu_(2) * (0.1 / np.sqrt(n))
     idx = torch.arange(npair, device=device) * 2
     a[:, idx, idx] = lam.real
     a[:, idx + 1, idx + 1] = lam.real

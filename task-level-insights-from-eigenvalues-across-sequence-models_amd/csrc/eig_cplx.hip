@@ -267,9 +267,16 @@ __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __res
                     HM(k + 1, j) = zsub(rb, zmul(sum, v2));
                 }
                 __syncthreads();                // also: every thread has read the bulge column by now
-                if (k > m && tid == 0) {
-                    HM(k, k - 1) = a0;
-                    HM(k + 1, k - 1) = {0.0, 0.0};
+                if (tid == 0) {
+                    if (k > m) {
+                        HM(k, k - 1) = a0;
+                        HM(k + 1, k - 1) = {0.0, 0.0};
+                    } else if (m > l) {
+                        // sweep started below a small (not yet negligible) subdiagonal: row m of column m-1 sees
+                        // the reflector too, H(m,m-1) <- (1 - conj(tau)) H(m,m-1); the fill-in below it is the
+                        // product of two small subdiagonals and is dropped (the xLAHQR start criterion)
+                        HM(k, k - 1) = zmul(HM(k, k - 1), {1.0 - tau.re, tau.im});
+                    }
                 }
                 // columns k, k+1, rows l..min(k+2,i):  r <- r H,  sum = tau (a + b v2)
                 const int rmax = (k + 2 < i) ? k + 2 : i;
@@ -329,8 +336,9 @@ int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, i
     const double* ap = static_cast<const double*>(a);
     double* wk = static_cast<double*>(workspace);
     auto launch = [&](auto kern) -> int {
-        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dyn > 48 * 1024)
+            EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL(kern, dim3((unsigned)nmat), dim3(kCThreads), dyn, stream, ap, n, lda, stride, w, info, wk);
         EGS_LAUNCH_CHECK();
         return 0;

@@ -309,8 +309,9 @@ static int skinny_launch(bool norm, const float* x, int64_t ntok, int d_model, i
     int64_t ntiles = (ntok + tile - 1) / tile;
     unsigned grid = (unsigned)(ntiles < 2048 ? ntiles : 2048);
     auto launch = [&](auto kern) -> int {
-        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (lds > 48 * 1024)
+            EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(kProjThreads), lds, stream, x, ntok, d_model, ldx, w, nh, tile,
                            mp, np);
         EGS_LAUNCH_CHECK();
