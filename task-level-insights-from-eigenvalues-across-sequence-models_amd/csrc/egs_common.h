@@ -36,9 +36,17 @@ inline hipStream_t as_stream(egs_stream_t s) { return reinterpret_cast<hipStream
 // LDS traffic of one wavefront is executed in order, so cross-lane hand-offs through LDS inside a wave
 // only need the compiler not to reorder the accesses: a wavefront-scope fence.
 __device__ __forceinline__ void wave_lds_sync() {
+#ifdef EGS_WAVE_SYNC_FENCE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    // compiler-only ordering: DS instructions of one wave are issued and executed in program order, so no
+    // s_waitcnt is needed between a lane's LDS store and another lane's later load of it
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#endif
 }
 
 // Broadcast lane `src` (wave-uniform) of a double to every lane through two v_readlane_b32.

@@ -25,7 +25,8 @@ struct MatView {
 // Hessenberg reduction (unblocked, xGEHD2-style), one wave per matrix, full n x ld layout in LDS.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kHessLd = 65;            // odd leading dimension: row and column sweeps conflict-free
-constexpr int kHessWaves = 4;          // matrices per workgroup (4 x 33,280 B = 133 KB LDS)
+constexpr int kHessWaves = 4;          // matrices per workgroup (4 x 33,792 B = 135 KB LDS)
+constexpr int kHessStride = kWave * kHessLd + kWave;   // matrix + Householder vector, in doubles
 
 __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     const double* __restrict__ a, int64_t nmat, int n, int lda, int64_t stride, double* __restrict__ hout) {
@@ -34,17 +35,31 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     const int wave = threadIdx.x / kWave;
     const int64_t mat = (int64_t)blockIdx.x * kHessWaves + wave;
     if (mat >= nmat) return;                       // whole wave exits; no workgroup barriers are used
-    double* s = smem + (size_t)wave * (kWave * kHessLd);
+    double* s = smem + (size_t)wave * kHessStride;
+    double* vs = s + kWave * kHessLd;              // Householder vector, broadcast-read by the update loops
     const double* src = a + mat * stride;
+    const int lc = (lane < n) ? lane : (n - 1);    // clamped lane: loads always hit a valid element
+    const bool inr = lane < n;
 
-    // coalesced load: consecutive lanes read consecutive elements of a row
-    for (int i = 0; i < n; ++i)
-        if (lane < n) s[i * kHessLd + lane] = src[(int64_t)i * lda + lane];
+    // coalesced load: consecutive lanes read consecutive elements of a row; 8 rows in flight
+    {
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(i + u) * lda + lc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (inr) s[(i + u) * kHessLd + lane] = t[u];
+        }
+        for (; i < n; ++i)
+            if (inr) s[i * kHessLd + lane] = src[(int64_t)i * lda + lane];
+    }
     wave_lds_sync();
 
     for (int k = 0; k < n - 2; ++k) {
         // lane i holds x_i = A(i,k), i > k
-        const bool below = (lane > k) && (lane < n);
+        const bool below = (lane > k) && inr;
         const double xi = below ? s[lane * kHessLd + k] : 0.0;
         const double alpha = bcast_lane(xi, k + 1);
         const double xnorm2 = wave_sum((lane > k + 1) ? xi * xi : 0.0);
@@ -53,43 +68,85 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
         const double beta = -copysign(nrm, alpha);
         const double tau = (beta - alpha) / beta;
         const double scal = 1.0 / (alpha - beta);
-        const double v = (lane == k + 1) ? 1.0 : ((lane > k + 1 && lane < n) ? xi * scal : 0.0);
+        const double v = (lane == k + 1) ? 1.0 : ((lane > k + 1 && inr) ? xi * scal : 0.0);
         if (below) s[lane * kHessLd + k] = (lane == k + 1) ? beta : 0.0;
+        vs[lane] = v;
+        wave_lds_sync();
 
-        // left: A(k+1:, k+1:) -= tau v (v^T A)      lane = column j
+        // left: A(k+1:, k+1:) -= tau v (v^T A)      lane = column j; rows streamed 8 at a time
         {
-            const bool act = below;                 // j in k+1..n-1
-            double w = 0.0;
-#pragma unroll 4
-            for (int i = k + 1; i < n; ++i) {
-                const double vi = bcast_lane(v, i);
-                const double aij = act ? s[i * kHessLd + lane] : 0.0;
-                w = fma(vi, aij, w);
+            double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+            int i = k + 1;
+            for (; i + 8 <= n; i += 8) {
+                double av[8], vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = s[(i + u) * kHessLd + lc];
+                    vv[u] = vs[i + u];
+                }
+                w0 = fma(vv[0], av[0], w0);
+                w1 = fma(vv[1], av[1], w1);
+                w2 = fma(vv[2], av[2], w2);
+                w3 = fma(vv[3], av[3], w3);
+                w0 = fma(vv[4], av[4], w0);
+                w1 = fma(vv[5], av[5], w1);
+                w2 = fma(vv[6], av[6], w2);
+                w3 = fma(vv[7], av[7], w3);
             }
-            w *= tau;
-#pragma unroll 4
-            for (int i = k + 1; i < n; ++i) {
-                const double vi = bcast_lane(v, i);
-                if (act) s[i * kHessLd + lane] = fma(-vi, w, s[i * kHessLd + lane]);
+            for (; i < n; ++i) w0 = fma(vs[i], s[i * kHessLd + lc], w0);
+            const double w = ((w0 + w1) + (w2 + w3)) * tau;
+            i = k + 1;
+            for (; i + 8 <= n; i += 8) {
+                double av[8], vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = s[(i + u) * kHessLd + lc];
+                    vv[u] = vs[i + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (below) s[(i + u) * kHessLd + lane] = fma(-vv[u], w, av[u]);
             }
+            for (; i < n; ++i)
+                if (below) s[i * kHessLd + lane] = fma(-vs[i], w, s[i * kHessLd + lane]);
         }
         wave_lds_sync();
-        // right: A(:, k+1:) -= tau (A v) v^T        lane = row i
+        // right: A(:, k+1:) -= tau (A v) v^T        lane = row i; columns streamed 8 at a time
         {
-            const bool act = lane < n;
-            double u = 0.0;
-#pragma unroll 4
-            for (int j = k + 1; j < n; ++j) {
-                const double vj = bcast_lane(v, j);
-                const double aij = act ? s[lane * kHessLd + j] : 0.0;
-                u = fma(aij, vj, u);
+            double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+            int j = k + 1;
+            for (; j + 8 <= n; j += 8) {
+                double av[8], vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = s[lc * kHessLd + j + u];
+                    vv[u] = vs[j + u];
+                }
+                u0 = fma(vv[0], av[0], u0);
+                u1 = fma(vv[1], av[1], u1);
+                u2 = fma(vv[2], av[2], u2);
+                u3 = fma(vv[3], av[3], u3);
+                u0 = fma(vv[4], av[4], u0);
+                u1 = fma(vv[5], av[5], u1);
+                u2 = fma(vv[6], av[6], u2);
+                u3 = fma(vv[7], av[7], u3);
             }
-            u *= tau;
-#pragma unroll 4
-            for (int j = k + 1; j < n; ++j) {
-                const double vj = bcast_lane(v, j);
-                if (act) s[lane * kHessLd + j] = fma(-u, vj, s[lane * kHessLd + j]);
+            for (; j < n; ++j) u0 = fma(vs[j], s[lc * kHessLd + j], u0);
+            const double uu = ((u0 + u1) + (u2 + u3)) * tau;
+            j = k + 1;
+            for (; j + 8 <= n; j += 8) {
+                double av[8], vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = s[lc * kHessLd + j + u];
+                    vv[u] = vs[j + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (inr) s[lane * kHessLd + j + u] = fma(-uu, vv[u], av[u]);
             }
+            for (; j < n; ++j)
+                if (inr) s[lane * kHessLd + j] = fma(-uu, vs[j], s[lane * kHessLd + j]);
         }
         wave_lds_sync();
     }
@@ -97,7 +154,7 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     // store the Hessenberg matrix densely (exact zeros below the subdiagonal)
     double* dst = hout + mat * (int64_t)n * n;
     for (int i = 0; i < n; ++i)
-        if (lane < n) dst[(int64_t)i * n + lane] = (i > lane + 1) ? 0.0 : s[i * kHessLd + lane];
+        if (inr) dst[(int64_t)i * n + lane] = (i > lane + 1) ? 0.0 : s[i * kHessLd + lane];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -178,6 +235,100 @@ __device__ inline void lanv2_eig(double a, double b, double c, double d, double&
 // scalar quantities (shifts, reflectors, deflation decisions) are computed redundantly by every lane from
 // broadcast LDS reads; the O(n) row / column updates of a bulge step are spread over the lanes.
 // ---------------------------------------------------------------------------------------------------
+// xLARFG on (a0; a1, a2), branch-free: beta, tau t1 and the scaled tail (u1, u2).  A zero tail gives the identity
+// (t1 = 0) exactly like LAPACK; rsqrt / rcp seeds plus two Newton steps keep the reflector orthogonal to ~1 ulp.
+__device__ __forceinline__ void larfg3(double a0, double a1, double a2, double& beta, double& t1, double& u1,
+                                       double& u2) {
+    const double xs = fma(a1, a1, a2 * a2);
+    const double nrm2 = fma(a0, a0, xs);
+    const bool nz = xs != 0.0;
+    const double rn = fast_rsqrt(nz ? nrm2 : 1.0);        // 1/||a||
+    const double nrm = nrm2 * rn;
+    const double apn = fabs(a0) + nrm;                    // |a0 - beta|
+    const double scal = copysign(fast_rcp(nz ? apn : 1.0), a0);   // 1/(a0 - beta)
+    beta = nz ? -copysign(nrm, a0) : a0;
+    t1 = nz ? apn * rn : 0.0;                             // (beta - a0)/beta
+    u1 = nz ? a1 * scal : 0.0;
+    u2 = nz ? a2 * scal : 0.0;
+}
+
+// One order-3 bulge-chase step at row k (k <= i-2).  On entry (a0,a1,a2) is the bulge column H(k..k+2, k-1) (or the
+// start vector when FIRST); on exit it is the next bulge column H(k+1..k+3, k), forwarded through registers so the
+// critical path never waits for an LDS write -> read round trip.  All loads use clamped lane indices so the whole
+// step is one basic block up to the predicated stores (the row loads overlap the reflector arithmetic).
+template <bool FIRST>
+__device__ __forceinline__ void qr_step3(const MatView& H, int k, int l, int i, int lane, bool m_gt_l, double& a0,
+                                         double& a1, double& a2) {
+    const int jc = min(max(lane, k), i);                  // row op: columns k..i
+    const double r0 = H.at(k, jc);
+    const double r1 = H.at(k + 1, jc);
+    const double r2 = H.at(k + 2, jc);
+    double hkk1 = 0.0;
+    if (FIRST) hkk1 = m_gt_l ? H.at(k, k - 1) : 0.0;
+    double beta, t1, u1, u2;
+    larfg3(a0, a1, a2, beta, t1, u1, u2);
+    const double t2 = t1 * u1;
+    const double t3 = t1 * u2;
+    if (!FIRST) {
+        if (lane < 3) H.at(k + lane, k - 1) = (lane == 0) ? beta : 0.0;
+    } else if (m_gt_l) {
+        if (lane == 0) H.at(k, k - 1) = hkk1 * (1.0 - t1);
+    }
+    {
+        const double sum = fma(u2, r2, fma(u1, r1, r0));
+        if (lane >= k && lane <= i) {
+            H.at(k, lane) = fma(-sum, t1, r0);
+            H.at(k + 1, lane) = fma(-sum, t2, r1);
+            H.at(k + 2, lane) = fma(-sum, t3, r2);
+        }
+    }
+    wave_lds_sync();
+    const int rmax = (k + 3 < i) ? k + 3 : i;             // column op: rows l..min(k+3, i)
+    const int rc = min(max(lane, l), rmax);
+    const double c0 = H.at(rc, k);
+    const double c1 = H.at(rc, k + 1);
+    const double c2 = H.at(rc, k + 2);
+    const double sum = fma(u2, c2, fma(u1, c1, c0));
+    const double n0 = fma(-sum, t1, c0);
+    if (lane >= l && lane <= rmax) {
+        H.at(lane, k) = n0;
+        H.at(lane, k + 1) = fma(-sum, t2, c1);
+        H.at(lane, k + 2) = fma(-sum, t3, c2);
+    }
+    a0 = bcast_lane(n0, k + 1);
+    a1 = bcast_lane(n0, k + 2);
+    a2 = bcast_lane(n0, rmax);                            // row k+3; unused by the order-2 step when k+3 > i
+    wave_lds_sync();
+}
+
+// The final order-2 step of a sweep at row k = i-1: reflector from (a0, a1) = H(i-1..i, i-2).
+__device__ __forceinline__ void qr_step2(const MatView& H, int k, int l, int i, int lane, double a0, double a1) {
+    const int jc = min(max(lane, k), i);
+    const double r0 = H.at(k, jc);
+    const double r1 = H.at(k + 1, jc);
+    double beta, t1, u1, u2;
+    larfg3(a0, a1, 0.0, beta, t1, u1, u2);
+    const double t2 = t1 * u1;
+    if (lane < 2) H.at(k + lane, k - 1) = (lane == 0) ? beta : 0.0;
+    {
+        const double sum = fma(u1, r1, r0);
+        if (lane >= k && lane <= i) {
+            H.at(k, lane) = fma(-sum, t1, r0);
+            H.at(k + 1, lane) = fma(-sum, t2, r1);
+        }
+    }
+    wave_lds_sync();
+    const int rc = min(max(lane, l), i);                  // rows l..i
+    const double c0 = H.at(rc, k);
+    const double c1 = H.at(rc, k + 1);
+    const double sum = fma(u1, c1, c0);
+    if (lane >= l && lane <= i) {
+        H.at(lane, k) = fma(-sum, t1, c0);
+        H.at(lane, k + 1) = fma(-sum, t2, c1);
+    }
+    wave_lds_sync();
+}
+
 __device__ void hqr_wave(const MatView H, const int n, const int lane, double* __restrict__ w_out,
                          int32_t* __restrict__ info_out) {
     const double ulp = 2.220446049250313e-16;                      // dlamch('P')
@@ -317,63 +468,12 @@ __device__ void hqr_wave(const MatView H, const int n, const int lane, double* _
             v1 = bcast_lane(v1, m);
             v2 = bcast_lane(v2, m);
 
-            // ---- double-shift QR sweep: chase the bulge from row m to row i ----
-            for (int k = m; k < i; ++k) {
-                const bool three = (k < i - 1);                       // reflector order 3 (else 2)
-                double a0, a1, a2;
-                if (k > m) {
-                    a0 = H.at(k, k - 1);
-                    a1 = H.at(k + 1, k - 1);
-                    a2 = three ? H.at(k + 2, k - 1) : 0.0;
-                } else {
-                    a0 = v0;
-                    a1 = v1;
-                    a2 = v2;                                          // k == m implies three
-                }
-                // xLARFG on (a0; a1, a2)
-                const double xs = a1 * a1 + a2 * a2;
-                double t1 = 0.0, beta = a0, u1 = 0.0, u2 = 0.0;
-                if (xs != 0.0) {
-                    const double nrm2 = fma(a0, a0, xs);
-                    const double rn = fast_rsqrt(nrm2);               // 1/||a||
-                    const double nrm = nrm2 * rn;
-                    beta = -copysign(nrm, a0);
-                    const double apn = fabs(a0) + nrm;                // |a0 - beta|
-                    t1 = apn * rn;                                    // (beta - a0)/beta
-                    const double scal = copysign(fast_rcp(apn), a0);  // 1/(a0 - beta)
-                    u1 = a1 * scal;
-                    u2 = a2 * scal;
-                }
-                if (k > m) {
-                    if (lane < (three ? 3 : 2)) H.at(k + lane, k - 1) = (lane == 0) ? beta : 0.0;
-                } else if (m > l) {
-                    if (lane == 0) H.at(k, k - 1) = H.at(k, k - 1) * (1.0 - t1);
-                }
-                const double t2 = t1 * u1;
-                const double t3 = t1 * u2;
-                // row operation on rows k..k+2, columns k..i       (lane = column)
-                if (lane >= k && lane <= i) {
-                    const double r0 = H.at(k, lane);
-                    const double r1 = H.at(k + 1, lane);
-                    const double r2 = three ? H.at(k + 2, lane) : 0.0;
-                    const double sum = fma(u2, r2, fma(u1, r1, r0));
-                    H.at(k, lane) = fma(-sum, t1, r0);
-                    H.at(k + 1, lane) = fma(-sum, t2, r1);
-                    if (three) H.at(k + 2, lane) = fma(-sum, t3, r2);
-                }
-                wave_lds_sync();
-                // column operation on columns k..k+2, rows l..min(k+3,i)   (lane = row)
-                const int rmax = three ? ((k + 3 < i) ? k + 3 : i) : i;
-                if (lane >= l && lane <= rmax) {
-                    const double c0 = H.at(lane, k);
-                    const double c1 = H.at(lane, k + 1);
-                    const double c2 = three ? H.at(lane, k + 2) : 0.0;
-                    const double sum = fma(u2, c2, fma(u1, c1, c0));
-                    H.at(lane, k) = fma(-sum, t1, c0);
-                    H.at(lane, k + 1) = fma(-sum, t2, c1);
-                    if (three) H.at(lane, k + 2) = fma(-sum, t3, c2);
-                }
-                wave_lds_sync();
+            // ---- double-shift QR sweep: chase the bulge from row m to row i (m <= i-2) ----
+            {
+                double a0 = v0, a1 = v1, a2 = v2;
+                qr_step3<true>(H, m, l, i, lane, m > l, a0, a1, a2);
+                for (int k = m + 1; k <= i - 2; ++k) qr_step3<false>(H, k, l, i, lane, false, a0, a1, a2);
+                qr_step2(H, i - 1, l, i, lane, a0, a1);
             }
         }
         if (!converged) {
@@ -466,7 +566,7 @@ int hess_real_launch(const double* a, int64_t nmat, int n, int lda, int64_t stri
     if (nmat == 0 || n == 0) return 0;
     int st = set_lds_attrs();
     if (st) return st;
-    const size_t hess_lds = (size_t)kHessWaves * kWave * kHessLd * sizeof(double);
+    const size_t hess_lds = (size_t)kHessWaves * kHessStride * sizeof(double);
     const unsigned gh = (unsigned)((nmat + kHessWaves - 1) / kHessWaves);
     hipLaunchKernelGGL(hess_real_kernel, dim3(gh), dim3(kHessWaves * kWave), hess_lds, stream, a, nmat, n, lda, stride,
                        h);
