@@ -10,15 +10,23 @@
 // Replaces np.linalg.eigvals at analysis/eval_eig.py:296 for real batches (BASELINE config C2).
 // The QR kernel packs TWO Hessenberg matrices into one (n) x (n+7) LDS array -- one stored normally in
 // columns >= row+4, the other transposed in columns <= row+3 -- so 8 matrices fit in 145 KB of a CU's LDS.
+#include <stdlib.h>
+
 #include "egs_common.h"
 
 namespace egs {
 
-// element (i,j) of the wave's matrix lives at hm[i*sr + j*sc]
-struct MatView {
+// Element (i,j) of the wave's matrix lives at hm[i*sr + j*sc].  LDP > 0 fixes the pair-array leading dimension at
+// compile time (n = 64 -> 71) so that row / column neighbours become DS-instruction immediate offsets; LDP == 0 keeps
+// it in a register (any n <= 64).  TR selects the transposed member of a packed pair.
+template <int LDP, bool TR>
+struct MatViewT {
+    static constexpr bool kFast = LDP > 0;
     double* hm;
-    int sr, sc;
-    __device__ __forceinline__ double& at(int i, int j) const { return hm[i * sr + j * sc]; }
+    int ld;
+    __device__ __forceinline__ int sr() const { return TR ? 1 : (LDP > 0 ? LDP : ld); }
+    __device__ __forceinline__ int sc() const { return TR ? (LDP > 0 ? LDP : ld) : 1; }
+    __device__ __forceinline__ double& at(int i, int j) const { return hm[i * sr() + j * sc()]; }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -235,34 +243,45 @@ __device__ inline void lanv2_eig(double a, double b, double c, double d, double&
 // scalar quantities (shifts, reflectors, deflation decisions) are computed redundantly by every lane from
 // broadcast LDS reads; the O(n) row / column updates of a bulge step are spread over the lanes.
 // ---------------------------------------------------------------------------------------------------
-// xLARFG on (a0; a1, a2), branch-free: beta, tau t1 and the scaled tail (u1, u2).  A zero tail gives the identity
-// (t1 = 0) exactly like LAPACK; rsqrt / rcp seeds plus two Newton steps keep the reflector orthogonal to ~1 ulp.
+// xLARFG on (a0; a1, a2), branch- and select-free.  A zero tail gives H = diag(-1, 1, 1) (t1 = 2, u = 0) instead of
+// LAPACK's identity -- equally orthogonal, it only flips the sign of row/column k.  The two fmax guards keep an
+// all-zero column finite (t1 = 0, u = 0).  rsqrt / rcp seeds + Newton steps keep the reflector orthogonal to ~1 ulp.
 __device__ __forceinline__ void larfg3(double a0, double a1, double a2, double& beta, double& t1, double& u1,
                                        double& u2) {
+    const double tiny = 1e-300;
     const double xs = fma(a1, a1, a2 * a2);
     const double nrm2 = fma(a0, a0, xs);
-    const bool nz = xs != 0.0;
-    const double rn = fast_rsqrt(nz ? nrm2 : 1.0);        // 1/||a||
+    const double rn = fast_rsqrt(fmax(nrm2, tiny));       // 1/||a||
     const double nrm = nrm2 * rn;
     const double apn = fabs(a0) + nrm;                    // |a0 - beta|
-    const double scal = copysign(fast_rcp(nz ? apn : 1.0), a0);   // 1/(a0 - beta)
-    beta = nz ? -copysign(nrm, a0) : a0;
-    t1 = nz ? apn * rn : 0.0;                             // (beta - a0)/beta
-    u1 = nz ? a1 * scal : 0.0;
-    u2 = nz ? a2 * scal : 0.0;
+    const double scal = copysign(fast_rcp(fmax(apn, tiny)), a0);   // 1/(a0 - beta)
+    beta = -copysign(nrm, a0);
+    t1 = apn * rn;                                        // (beta - a0)/beta
+    u1 = a1 * scal;
+    u2 = a2 * scal;
 }
 
 // One order-3 bulge-chase step at row k (k <= i-2).  On entry (a0,a1,a2) is the bulge column H(k..k+2, k-1) (or the
 // start vector when FIRST); on exit it is the next bulge column H(k+1..k+3, k), forwarded through registers so the
-// critical path never waits for an LDS write -> read round trip.  All loads use clamped lane indices so the whole
-// step is one basic block up to the predicated stores (the row loads overlap the reflector arithmetic).
-template <bool FIRST>
-__device__ __forceinline__ void qr_step3(const MatView& H, int k, int l, int i, int lane, bool m_gt_l, double& a0,
-                                         double& a1, double& a2) {
-    const int jc = min(max(lane, k), i);                  // row op: columns k..i
-    const double r0 = H.at(k, jc);
-    const double r1 = H.at(k + 1, jc);
-    const double r2 = H.at(k + 2, jc);
+// critical path never waits for an LDS write -> read round trip.  rowp = &H(k, lane) and colp = &H(lane, k) advance
+// by one row / column per step.  In the fast (n = 64) layout every lane owns a real column / row, loads need no
+// clamping and the three row / column neighbours are immediate offsets; the generic layout clamps the lane index so
+// that loads always hit valid elements.  Only the stores are predicated.
+template <bool FIRST, class V>
+__device__ __forceinline__ void qr_step3(const V& H, double*& rowp, double*& colp, int k, int l, int i, int lane,
+                                         bool m_gt_l, double& a0, double& a1, double& a2) {
+    const int SR = H.sr(), SC = H.sc();
+    double r0, r1, r2;
+    if constexpr (V::kFast) {
+        r0 = rowp[0];
+        r1 = rowp[SR];
+        r2 = rowp[2 * SR];
+    } else {
+        const int jc = min(max(lane, k), i);              // row op: columns k..i
+        r0 = H.at(k, jc);
+        r1 = H.at(k + 1, jc);
+        r2 = H.at(k + 2, jc);
+    }
     double hkk1 = 0.0;
     if (FIRST) hkk1 = m_gt_l ? H.at(k, k - 1) : 0.0;
     double beta, t1, u1, u2;
@@ -277,32 +296,44 @@ __device__ __forceinline__ void qr_step3(const MatView& H, int k, int l, int i, 
     {
         const double sum = fma(u2, r2, fma(u1, r1, r0));
         if (lane >= k && lane <= i) {
-            H.at(k, lane) = fma(-sum, t1, r0);
-            H.at(k + 1, lane) = fma(-sum, t2, r1);
-            H.at(k + 2, lane) = fma(-sum, t3, r2);
+            double* wp = V::kFast ? rowp : &H.at(k, lane);
+            wp[0] = fma(-sum, t1, r0);
+            wp[SR] = fma(-sum, t2, r1);
+            wp[2 * SR] = fma(-sum, t3, r2);
         }
     }
     wave_lds_sync();
     const int rmax = (k + 3 < i) ? k + 3 : i;             // column op: rows l..min(k+3, i)
-    const int rc = min(max(lane, l), rmax);
-    const double c0 = H.at(rc, k);
-    const double c1 = H.at(rc, k + 1);
-    const double c2 = H.at(rc, k + 2);
+    double c0, c1, c2;
+    if constexpr (V::kFast) {
+        c0 = colp[0];
+        c1 = colp[SC];
+        c2 = colp[2 * SC];
+    } else {
+        const int rc = min(max(lane, l), rmax);
+        c0 = H.at(rc, k);
+        c1 = H.at(rc, k + 1);
+        c2 = H.at(rc, k + 2);
+    }
     const double sum = fma(u2, c2, fma(u1, c1, c0));
     const double n0 = fma(-sum, t1, c0);
     if (lane >= l && lane <= rmax) {
-        H.at(lane, k) = n0;
-        H.at(lane, k + 1) = fma(-sum, t2, c1);
-        H.at(lane, k + 2) = fma(-sum, t3, c2);
+        double* wp = V::kFast ? colp : &H.at(lane, k);
+        wp[0] = n0;
+        wp[SC] = fma(-sum, t2, c1);
+        wp[2 * SC] = fma(-sum, t3, c2);
     }
     a0 = bcast_lane(n0, k + 1);
     a1 = bcast_lane(n0, k + 2);
     a2 = bcast_lane(n0, rmax);                            // row k+3; unused by the order-2 step when k+3 > i
+    rowp += SR;
+    colp += SC;
     wave_lds_sync();
 }
 
 // The final order-2 step of a sweep at row k = i-1: reflector from (a0, a1) = H(i-1..i, i-2).
-__device__ __forceinline__ void qr_step2(const MatView& H, int k, int l, int i, int lane, double a0, double a1) {
+template <class V>
+__device__ __forceinline__ void qr_step2(const V& H, int k, int l, int i, int lane, double a0, double a1) {
     const int jc = min(max(lane, k), i);
     const double r0 = H.at(k, jc);
     const double r1 = H.at(k + 1, jc);
@@ -329,7 +360,8 @@ __device__ __forceinline__ void qr_step2(const MatView& H, int k, int l, int i, 
     wave_lds_sync();
 }
 
-__device__ void hqr_wave(const MatView H, const int n, const int lane, double* __restrict__ w_out,
+template <class V>
+__device__ void hqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
                          int32_t* __restrict__ info_out) {
     const double ulp = 2.220446049250313e-16;                      // dlamch('P')
     const double safmin = 2.2250738585072014e-308;
@@ -471,8 +503,10 @@ __device__ void hqr_wave(const MatView H, const int n, const int lane, double* _
             // ---- double-shift QR sweep: chase the bulge from row m to row i (m <= i-2) ----
             {
                 double a0 = v0, a1 = v1, a2 = v2;
-                qr_step3<true>(H, m, l, i, lane, m > l, a0, a1, a2);
-                for (int k = m + 1; k <= i - 2; ++k) qr_step3<false>(H, k, l, i, lane, false, a0, a1, a2);
+                double* rowp = &H.at(m, lane);
+                double* colp = &H.at(lane, m);
+                qr_step3<true>(H, rowp, colp, m, l, i, lane, m > l, a0, a1, a2);
+                for (int k = m + 1; k <= i - 2; ++k) qr_step3<false>(H, rowp, colp, k, l, i, lane, false, a0, a1, a2);
                 qr_step2(H, i - 1, l, i, lane, a0, a1);
             }
         }
@@ -517,6 +551,17 @@ __host__ __device__ inline int hqr_pair_ld(int n) {
     return (ld & 1) ? ld : ld + 1;
 }
 
+template <class V>
+__device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ src, int n, int lane,
+                                        double* __restrict__ wo, int32_t* __restrict__ info) {
+    // load the Hessenberg part plus the two extra sub-diagonals a bulge may touch (zeros)
+    for (int i = 0; i < n; ++i) {
+        if (lane < n && i <= lane + 3) H.at(i, lane) = (i <= lane + 1) ? src[(int64_t)i * n + lane] : 0.0;
+    }
+    wave_lds_sync();
+    hqr_wave(H, n, lane, wo, info);
+}
+
 __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
                                                        double* __restrict__ w, int32_t* __restrict__ info,
                                                        int waves_per_block) {
@@ -527,23 +572,15 @@ __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict_
     if (mat >= nmat) return;
     const int ldp = hqr_pair_ld(n);
     double* base = smem + (size_t)(wave >> 1) * ((size_t)n * ldp);
-    MatView H;
-    if ((wave & 1) == 0) {
-        H.hm = base + 7;
-        H.sr = ldp;
-        H.sc = 1;
-    } else {
-        H.hm = base;
-        H.sr = 1;
-        H.sc = ldp;
-    }
-    // load the Hessenberg part plus the three sub-diagonals a bulge may touch (zeros)
     const double* src = hin + mat * (int64_t)n * n;
-    for (int i = 0; i < n; ++i) {
-        if (lane < n && i <= lane + 3) H.at(i, lane) = (i <= lane + 1) ? src[(int64_t)i * n + lane] : 0.0;
+    double* wo = w + mat * 2 * (int64_t)n;
+    if (n == 64) {
+        if ((wave & 1) == 0) hqr_run(MatViewT<71, false>{base + 7, ldp}, src, n, lane, wo, info + mat);
+        else hqr_run(MatViewT<71, true>{base, ldp}, src, n, lane, wo, info + mat);
+    } else {
+        if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat);
+        else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat);
     }
-    wave_lds_sync();
-    hqr_wave(H, n, lane, w + mat * 2 * (int64_t)n, info + mat);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -583,6 +620,10 @@ int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* in
     int pairs = (int)((160 * 1024) / pair_bytes);
     if (pairs > 4) pairs = 4;
     if (pairs < 1) pairs = 1;
+    if (const char* e = getenv("EGS_HQR_PAIRS")) {          // tuning knob (occupancy experiments)
+        const int v = atoi(e);
+        if (v >= 1 && v < pairs) pairs = v;
+    }
     const int hqr_waves = 2 * pairs;
     const size_t hqr_lds = pairs * pair_bytes;
     const unsigned gq = (unsigned)((nmat + hqr_waves - 1) / hqr_waves);
