@@ -198,6 +198,105 @@ __global__ __launch_bounds__(kProjThreads) void skinny_proj_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K2 fast path (common Mamba-2 shapes: D = 4*G*C with G in {16,32,64} lanes per token, nheads <= 8).
+// Every wave streams blocks of TPW*U consecutive tokens: all U*C 16-byte loads of a lane are issued first
+// (memory-level parallelism), W lives in registers, the U*NH partial dots per lane are combined across the G lanes
+// of a token with a transpose-reduce (each butterfly step halves the values a lane carries: U*NH + log2 shuffles
+// instead of U*NH*log2(G)), and the lane that ends up owning (token u, head h) runs the fused softplus/exp epilogue
+// and stores out[tok][h] -- consecutive owners write consecutive addresses.  No LDS, no workgroup barrier.
+// ---------------------------------------------------------------------------------------------------
+// Transpose-reduce: CNT partial sums per lane, butterfly over xor offsets OFF, OFF/2, ..., 1.  While a lane still
+// carries more than one value, a step sends the half it gives up and keeps the other half (upper lanes keep the
+// upper half), so after log2(CNT) steps lane gl holds the complete sum of value index (top bits of gl).
+template <int CNT, int OFF>
+__device__ __forceinline__ void treduce(float* v, int gl) {
+    if constexpr (OFF >= 1) {
+        const bool upper = (gl & OFF) != 0;
+        if constexpr (CNT > 1) {
+            constexpr int H = CNT / 2;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const float send = upper ? v[i] : v[i + H];
+                const float keep = upper ? v[i + H] : v[i];
+                v[i] = keep + __shfl_xor(send, OFF, 64);
+            }
+            treduce<H, OFF / 2>(v, gl);
+        } else {
+            v[0] += __shfl_xor(v[0], OFF, 64);
+            treduce<1, OFF / 2>(v, gl);
+        }
+    }
+}
+
+template <int G, int C, int NH>
+__global__ __launch_bounds__(256) void mamba2_lambda_fast_kernel(const float* __restrict__ x, int64_t ntok, int64_t ldx,
+                                                                 const float* __restrict__ w, int nh_real,
+                                                                 const float* __restrict__ b_dt,
+                                                                 const float* __restrict__ dt_bias,
+                                                                 const float* __restrict__ a_log,
+                                                                 float* __restrict__ out) {
+    constexpr int D = 4 * G * C;
+    constexpr int TPW = 64 / G;                       // tokens side by side in one wave
+    constexpr int U = (G / NH) < 4 ? (G / NH) : 4;    // tokens per lane group per iteration (U*NH <= G)
+    constexpr int V = U * NH;                         // partial sums per lane
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int grp = lane / G;
+    // W slice of this lane, zero rows for the padded heads
+    float4 wr[NH][C];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            wr[h][c] = (h < nh_real) ? *reinterpret_cast<const float4*>(w + (int64_t)h * D + (c * G + gl) * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    // after the transpose-reduce lane gl owns value index gl / (G / V) = u * NH + h
+    constexpr int OWN = G / V;
+    const int idx = gl / OWN;
+    const int my_u = idx / NH, my_h = idx % NH;
+    const bool owner = (gl % OWN) == 0 && my_h < nh_real;
+    float bias_h = 0.f, a_h = 0.f;
+    if (my_h < nh_real) {
+        bias_h = dt_bias[my_h] + (b_dt ? b_dt[my_h] : 0.f);
+        a_h = -expf(a_log[my_h]);
+    }
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int TOK_PER_IT = TPW * U;
+    for (int64_t t0 = wave_id * TOK_PER_IT; t0 < ntok; t0 += nwaves * TOK_PER_IT) {
+        float4 xv[U][C];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t tok = t0 + grp * U + u;
+            const float* xr = x + (tok < ntok ? tok : 0) * ldx;
+#pragma unroll
+            for (int c = 0; c < C; ++c) xv[u][c] = *reinterpret_cast<const float4*>(xr + (c * G + gl) * 4);
+        }
+        float v[V];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    acc = fmaf(xv[u][c].x, wr[h][c].x, acc);
+                    acc = fmaf(xv[u][c].y, wr[h][c].y, acc);
+                    acc = fmaf(xv[u][c].z, wr[h][c].z, acc);
+                    acc = fmaf(xv[u][c].w, wr[h][c].w, acc);
+                }
+                v[u * NH + h] = acc;
+            }
+        treduce<V, G / 2>(v, gl);          // transpose-reduce across the G lanes of the token group
+        const int64_t tok = t0 + grp * U + my_u;
+        if (owner && tok < ntok) {
+            const float dt = softplus_f32(v[0] + bias_h);           // analysis/eval_eig.py:182
+            out[tok * nh_real + my_h] = expf(dt * a_h);             // :184
+        }
+    }
+}
+
 __global__ void mamba2_lti_kernel(const float* __restrict__ a_param, const float* __restrict__ beta, int nh,
                                   int64_t ntok, float* __restrict__ out) {
     // exp(beta * -softplus(A)) broadcast over tokens (analysis/eval_eig.py:194-199)
@@ -321,9 +420,41 @@ static int skinny_launch(bool norm, const float* x, int64_t ntok, int d_model, i
     return vec4 ? launch(skinny_proj_kernel<4, false>) : launch(skinny_proj_kernel<1, false>);
 }
 
+template <int G, int C>
+static int mamba2_fast_dispatch(int nh_pad, const float* x, int64_t ntok, int64_t ldx, const float* w, int nh,
+                                const float* b_dt, const float* dt_bias, const float* a_log, float* out,
+                                hipStream_t stream) {
+    constexpr int tok_per_block = 4 * (64 / G) * 4;
+    int64_t blocks = (ntok + tok_per_block - 1) / tok_per_block;
+    const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+    switch (nh_pad) {
+        case 1: hipLaunchKernelGGL((mamba2_lambda_fast_kernel<G, C, 1>), dim3(grid), dim3(256), 0, stream, x, ntok, ldx, w, nh, b_dt, dt_bias, a_log, out); break;
+        case 2: hipLaunchKernelGGL((mamba2_lambda_fast_kernel<G, C, 2>), dim3(grid), dim3(256), 0, stream, x, ntok, ldx, w, nh, b_dt, dt_bias, a_log, out); break;
+        case 4: hipLaunchKernelGGL((mamba2_lambda_fast_kernel<G, C, 4>), dim3(grid), dim3(256), 0, stream, x, ntok, ldx, w, nh, b_dt, dt_bias, a_log, out); break;
+        default: hipLaunchKernelGGL((mamba2_lambda_fast_kernel<G, C, 8>), dim3(grid), dim3(256), 0, stream, x, ntok, ldx, w, nh, b_dt, dt_bias, a_log, out); break;
+    }
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
 int mamba2_lambda_launch(const float* x, int64_t ntok, int d_model, int64_t ldx, const float* w_dt,
                          const float* b_dt, const float* dt_bias, const float* a_log, int nheads, float* out,
                          hipStream_t stream) {
+    if (ntok == 0) return 0;
+    const bool aligned = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(w_dt) & 15) == 0);
+    if (aligned && nheads <= 8) {
+        int nh_pad = 1;
+        while (nh_pad < nheads) nh_pad <<= 1;
+        switch (d_model) {
+            case 64: return mamba2_fast_dispatch<16, 1>(nh_pad, x, ntok, ldx, w_dt, nheads, b_dt, dt_bias, a_log, out, stream);
+            case 128: return mamba2_fast_dispatch<32, 1>(nh_pad, x, ntok, ldx, w_dt, nheads, b_dt, dt_bias, a_log, out, stream);
+            case 256: return mamba2_fast_dispatch<64, 1>(nh_pad, x, ntok, ldx, w_dt, nheads, b_dt, dt_bias, a_log, out, stream);
+            case 512: return mamba2_fast_dispatch<64, 2>(nh_pad, x, ntok, ldx, w_dt, nheads, b_dt, dt_bias, a_log, out, stream);
+            case 1024: return mamba2_fast_dispatch<64, 4>(nh_pad, x, ntok, ldx, w_dt, nheads, b_dt, dt_bias, a_log, out, stream);
+            default: break;
+        }
+    }
     Mamba2Params mp{b_dt, dt_bias, a_log, out};
     NormParams np{nullptr, nullptr, 0, 1, nullptr};
     return skinny_launch(false, x, ntok, d_model, ldx, w_dt, nheads, mp, np, stream);
