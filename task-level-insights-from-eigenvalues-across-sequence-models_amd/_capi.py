@@ -7,7 +7,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeigspec_hip.so")
+# EGS_LIB_PATH selects another build of the same library (A/B tuning runs); the default is the in-tree build
+LIB_PATH = os.environ.get("EGS_LIB_PATH") or os.path.join(_HERE, "libeigspec_hip.so")
 
 # constants mirrored from include/eigspec.h
 EGS_ERR_RUNTIME = -1000

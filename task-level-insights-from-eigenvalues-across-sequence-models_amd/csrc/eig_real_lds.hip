@@ -34,7 +34,13 @@ struct MatViewT {
 // ---------------------------------------------------------------------------------------------------
 constexpr int kHessLd = 65;            // odd leading dimension: row and column sweeps conflict-free
 constexpr int kHessWaves = 4;          // matrices per workgroup (4 x 33,792 B = 135 KB LDS)
-constexpr int kHessStride = kWave * kHessLd + kWave;   // matrix + Householder vector, in doubles
+constexpr int kHessStride = kWave * kHessLd + 2 * kWave;   // matrix + Householder vector v + update vector y, in doubles
+// the Householder entry v_i is wave-uniform: either a broadcast LDS read or two v_readlane of the lane-held copy
+#ifdef EGS_HESS_V_READLANE
+#define HESS_V(idx) bcast_lane(v, (idx))
+#else
+#define HESS_V(idx) vs[(idx)]
+#endif
 
 __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     const double* __restrict__ a, int64_t nmat, int n, int lda, int64_t stride, double* __restrict__ hout) {
@@ -45,6 +51,7 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     if (mat >= nmat) return;                       // whole wave exits; no workgroup barriers are used
     double* s = smem + (size_t)wave * kHessStride;
     double* vs = s + kWave * kHessLd;              // Householder vector, broadcast-read by the update loops
+    double* ys = vs + kWave;                       // y of the rank-2 update
     const double* src = a + mat * stride;
     const int lc = (lane < n) ? lane : (n - 1);    // clamped lane: loads always hit a valid element
     const bool inr = lane < n;
@@ -81,80 +88,58 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
         vs[lane] = v;
         wave_lds_sync();
 
-        // left: A(k+1:, k+1:) -= tau v (v^T A)      lane = column j; rows streamed 8 at a time
+        // Two-sided update as ONE rank-2 pass:  H A H = A - w v^T - v y^T  with  p = A v,  q = A^T v,
+        // a2 = v^T p,  w = tau p - (tau^2 a2 / 2) v,  y = tau q - (tau^2 a2 / 2) v.
+        // Pass 1 (read-only) streams index t = k+1..n-1 once for both products: lane = row i reads A(i,t) for p_i,
+        // lane = column j reads A(t,j) for q_j.  Pass 2 updates A(i, k+1:) with lane = row.
+        double p0 = 0.0, p1 = 0.0, q0 = 0.0, q1 = 0.0;
         {
-            double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
-            int i = k + 1;
-            for (; i + 8 <= n; i += 8) {
-                double av[8], vv[8];
+            int t = k + 1;
+            for (; t + 8 <= n; t += 8) {
+                double ar[8], ac[8], vv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    av[u] = s[(i + u) * kHessLd + lc];
-                    vv[u] = vs[i + u];
-                }
-                w0 = fma(vv[0], av[0], w0);
-                w1 = fma(vv[1], av[1], w1);
-                w2 = fma(vv[2], av[2], w2);
-                w3 = fma(vv[3], av[3], w3);
-                w0 = fma(vv[4], av[4], w0);
-                w1 = fma(vv[5], av[5], w1);
-                w2 = fma(vv[6], av[6], w2);
-                w3 = fma(vv[7], av[7], w3);
-            }
-            for (; i < n; ++i) w0 = fma(vs[i], s[i * kHessLd + lc], w0);
-            const double w = ((w0 + w1) + (w2 + w3)) * tau;
-            i = k + 1;
-            for (; i + 8 <= n; i += 8) {
-                double av[8], vv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    av[u] = s[(i + u) * kHessLd + lc];
-                    vv[u] = vs[i + u];
+                    ar[u] = s[lc * kHessLd + t + u];        // A(lane, t+u)
+                    ac[u] = s[(t + u) * kHessLd + lc];      // A(t+u, lane)
+                    vv[u] = vs[t + u];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (below) s[(i + u) * kHessLd + lane] = fma(-vv[u], w, av[u]);
+                for (int u = 0; u < 8; u += 2) {
+                    p0 = fma(ar[u], vv[u], p0);
+                    q0 = fma(ac[u], vv[u], q0);
+                    p1 = fma(ar[u + 1], vv[u + 1], p1);
+                    q1 = fma(ac[u + 1], vv[u + 1], q1);
+                }
             }
-            for (; i < n; ++i)
-                if (below) s[i * kHessLd + lane] = fma(-vs[i], w, s[i * kHessLd + lane]);
+            for (; t < n; ++t) {
+                const double vt = vs[t];
+                p0 = fma(s[lc * kHessLd + t], vt, p0);
+                q0 = fma(s[t * kHessLd + lc], vt, q0);
+            }
         }
+        const double pi = inr ? (p0 + p1) : 0.0;
+        const double qj = below ? (q0 + q1) : 0.0;                 // only columns j > k are updated
+        const double a2 = wave_sum(v * pi);
+        const double corr = 0.5 * tau * tau * a2;
+        const double wv = fma(tau, pi, -corr * v);                  // w_i, lane = row i
+        ys[lane] = fma(tau, qj, -corr * v);                         // y_j, lane = column j
         wave_lds_sync();
-        // right: A(:, k+1:) -= tau (A v) v^T        lane = row i; columns streamed 8 at a time
         {
-            double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
             int j = k + 1;
             for (; j + 8 <= n; j += 8) {
-                double av[8], vv[8];
+                double av[8], vv[8], yy[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     av[u] = s[lc * kHessLd + j + u];
                     vv[u] = vs[j + u];
-                }
-                u0 = fma(vv[0], av[0], u0);
-                u1 = fma(vv[1], av[1], u1);
-                u2 = fma(vv[2], av[2], u2);
-                u3 = fma(vv[3], av[3], u3);
-                u0 = fma(vv[4], av[4], u0);
-                u1 = fma(vv[5], av[5], u1);
-                u2 = fma(vv[6], av[6], u2);
-                u3 = fma(vv[7], av[7], u3);
-            }
-            for (; j < n; ++j) u0 = fma(vs[j], s[lc * kHessLd + j], u0);
-            const double uu = ((u0 + u1) + (u2 + u3)) * tau;
-            j = k + 1;
-            for (; j + 8 <= n; j += 8) {
-                double av[8], vv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    av[u] = s[lc * kHessLd + j + u];
-                    vv[u] = vs[j + u];
+                    yy[u] = ys[j + u];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (inr) s[lane * kHessLd + j + u] = fma(-uu, vv[u], av[u]);
+                    if (inr) s[lane * kHessLd + j + u] = fma(-v, yy[u], fma(-wv, vv[u], av[u]));
             }
             for (; j < n; ++j)
-                if (inr) s[lane * kHessLd + j] = fma(-uu, vs[j], s[lane * kHessLd + j]);
+                if (inr) s[lane * kHessLd + j] = fma(-v, ys[j], fma(-wv, vs[j], s[lane * kHessLd + j]));
         }
         wave_lds_sync();
     }
