@@ -78,40 +78,246 @@ __global__ __launch_bounds__(256) void qk_proj_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 1b. the same projection on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32: bit-for-bit a k-ordered fmaf
+// chain, MI355X_MICROARCH "FP32-input MFMA").  This is the one genuinely dense contraction of the attention path
+// (AI = d_qk flop/B, above the fp32 ridge), so it is the place where MFMA is the right tool.
+//   workgroup 256 threads = 4 waves as 2 x 2, block tile 128 x 128, each wave 64 x 64 = 2 x 2 MFMA tiles (64 acc VGPRs)
+//   K staged 32 at a time through LDS as [k][row] so that an operand fragment (lane l: row l&31, k l>>5) is a
+//   conflict-free ds_read_b32; next stage prefetched into registers while the current one is multiplied.
+// Operand / accumulator lane maps (cdna_hip_programming.md section 3):  A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+//   D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMT = 128, kMK = 32, kMLd = kMT + 4;
+
+template <bool PHI>
+__global__ __launch_bounds__(256) void qk_proj_mfma_kernel(const float* __restrict__ x, int64_t m_rows, int d_model,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           int n_cols, float* __restrict__ out) {
+    __shared__ float as[kMK][kMLd];
+    __shared__ float bs[kMK][kMLd];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t row0 = (int64_t)blockIdx.x * kMT;
+    const int col0 = blockIdx.y * kMT;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // register prefetch buffers: thread t stages rows (t + 256 e) >> 3, k-quad (t & 7)
+    float4 xa0, xa1, xa2, xa3, wb0, wb1, wb2, wb3;
+    const int sr = tid >> 3, skq = tid & 7;
+#define EGS_GLOAD_ONE(XA, WB, E, K0)                                                                                 \
+    {                                                                                                                \
+        const int r_ = sr + 32 * (E);                                                                                \
+        const int gk_ = (K0) + skq * 4;                                                                              \
+        const int64_t gr_ = row0 + r_;                                                                               \
+        const int gc_ = col0 + r_;                                                                                   \
+        const bool okx_ = gr_ < m_rows && gk_ < d_model;                                                             \
+        const bool okw_ = gc_ < n_cols && gk_ < d_model;                                                             \
+        /* always load from a valid address, then zero by value (a pointer select would go through scratch) */      \
+        XA = *reinterpret_cast<const float4*>(x + (okx_ ? gr_ * d_model + gk_ : 0));                                 \
+        WB = *reinterpret_cast<const float4*>(w + (okw_ ? (int64_t)gc_ * d_model + gk_ : 0));                        \
+        if (!okx_) XA = make_float4(0.f, 0.f, 0.f, 0.f);                                                             \
+        if (!okw_) WB = make_float4(0.f, 0.f, 0.f, 0.f);                                                             \
+    }
+#define EGS_GLOAD(K0)                  \
+    EGS_GLOAD_ONE(xa0, wb0, 0, K0)     \
+    EGS_GLOAD_ONE(xa1, wb1, 1, K0)     \
+    EGS_GLOAD_ONE(xa2, wb2, 2, K0)     \
+    EGS_GLOAD_ONE(xa3, wb3, 3, K0)
+#define EGS_SSTORE_ONE(XA, WB, E)              \
+    {                                          \
+        const int r_ = sr + 32 * (E);          \
+        as[skq * 4 + 0][r_] = XA.x;            \
+        as[skq * 4 + 1][r_] = XA.y;            \
+        as[skq * 4 + 2][r_] = XA.z;            \
+        as[skq * 4 + 3][r_] = XA.w;            \
+        bs[skq * 4 + 0][r_] = WB.x;            \
+        bs[skq * 4 + 1][r_] = WB.y;            \
+        bs[skq * 4 + 2][r_] = WB.z;            \
+        bs[skq * 4 + 3][r_] = WB.w;            \
+    }
+#define EGS_SSTORE()               \
+    EGS_SSTORE_ONE(xa0, wb0, 0)    \
+    EGS_SSTORE_ONE(xa1, wb1, 1)    \
+    EGS_SSTORE_ONE(xa2, wb2, 2)    \
+    EGS_SSTORE_ONE(xa3, wb3, 3)
+    EGS_GLOAD(0)
+    for (int k0 = 0; k0 < d_model; k0 += kMK) {
+        __syncthreads();                     // everyone is done reading the previous stage
+        EGS_SSTORE()
+        __syncthreads();
+        if (k0 + kMK < d_model) { EGS_GLOAD(k0 + kMK) }
+        const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int k2 = 0; k2 < kMK / 2; ++k2) {
+            const float a0 = as[2 * k2 + kh][wm * 64 + l31];
+            const float a1 = as[2 * k2 + kh][wm * 64 + 32 + l31];
+            const float b0 = bs[2 * k2 + kh][wn * 64 + l31];
+            const float b1 = bs[2 * k2 + kh][wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int gc = col0 + wn * 64 + tn * 32 + l31;
+            const float bv = (bias && gc < n_cols) ? bias[gc] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t gr = row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (gr < m_rows && gc < n_cols) {
+                    float v = acc[tm][tn][r] + bv;
+                    if (PHI) v = elu1_f32(v);
+                    out[gr * n_cols + gc] = v;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 2a. linear attention scan: one wavefront per (b, h); lane d holds the running sum of phi(k)[d] in fp64
 // ---------------------------------------------------------------------------------------------------
+// Transpose-reduce over the 64 lanes (see stream_kernels.hip): CNT values per lane in, lane l ends with the complete
+// sum of value index l (for CNT = 64).
+template <typename T, int CNT, int OFF>
+__device__ __forceinline__ void treduce_t(T* v, int lane) {
+    if constexpr (OFF >= 1) {
+        const bool upper = (lane & OFF) != 0;
+        if constexpr (CNT > 1) {
+            constexpr int H = CNT / 2;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const T send = upper ? v[i] : v[i + H];
+                const T keep = upper ? v[i + H] : v[i];
+                v[i] = keep + __shfl_xor(send, OFF, 64);
+            }
+            treduce_t<T, H, OFF / 2>(v, lane);
+        } else {
+            v[0] += __shfl_xor(v[0], OFF, 64);
+            treduce_t<T, 1, OFF / 2>(v, lane);
+        }
+    }
+}
+
+// One wavefront per (b, h); lane d carries the fp64 running sum of phi(k)[d].  Tokens are processed 16 at a time:
+// the 16 per-lane products q_t[d] * S_t[d] are combined across the 64 lanes with one transpose-reduce (15 + 2 exchanges
+// instead of 16 x 6), after which 4-lane groups hold nu for one token each and the store is coalesced.
+// The sequence is cut into chunks of kScanChunk tokens so that B*H*L/kScanChunk wavefronts run concurrently:
+// linattn_chunksum_kernel produces each chunk's own sum of phi(k) (fp64), the scan kernel adds the sums of the preceding
+// chunks as its carry-in.
+constexpr int kScanChunk = 256;
+
+template <int J>
+__global__ __launch_bounds__(256) void linattn_chunksum_kernel(const float* __restrict__ qk, int64_t nseq, int64_t seqlen,
+                                                               int d_qk, int num_heads, int nchunks,
+                                                               double* __restrict__ csum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (b, h, chunk)
+    if (task >= nseq * num_heads * nchunks) return;
+    const int64_t pair = task / nchunks;
+    const int chunk = (int)(task - pair * nchunks);
+    const int64_t b = pair / num_heads;
+    const int h = (int)(pair - b * num_heads);
+    const int hd = d_qk / num_heads;
+    const float* base = qk + b * seqlen * 2 * d_qk + d_qk + (int64_t)h * hd;            // k rows
+    const int64_t t_begin = (int64_t)chunk * kScanChunk;
+    const int64_t t_end = (t_begin + kScanChunk < seqlen) ? t_begin + kScanChunk : seqlen;
+    double acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = 0.0;
+    for (int64_t t = t_begin; t < t_end; t += 8) {
+        float kv[8][J];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t tt = (t + u < t_end) ? t + u : t_end - 1;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int d = lane + 64 * j;
+                kv[u][j] = (d < hd && t + u < t_end) ? base[tt * 2 * d_qk + (d < hd ? d : 0)] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[j] += (double)kv[u][j];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int d = lane + 64 * j;
+        if (d < hd) csum[task * hd + d] = acc[j];
+    }
+}
+
 template <int J>   // head_dim <= 64*J
 __global__ __launch_bounds__(256) void linattn_scan_kernel(const float* __restrict__ qk, int64_t nseq, int64_t seqlen,
-                                                           int d_qk, int num_heads, double* __restrict__ nu) {
+                                                           int d_qk, int num_heads, int nchunks,
+                                                           const double* __restrict__ csum, double* __restrict__ nu) {
     const int lane = threadIdx.x & 63;
-    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (b, h)
-    if (pair >= nseq * num_heads) return;
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (b, h, chunk)
+    if (task >= nseq * num_heads * nchunks) return;
+    const int64_t pair = task / nchunks;
+    const int chunk = (int)(task - pair * nchunks);
     const int64_t b = pair / num_heads;
     const int h = (int)(pair - b * num_heads);
     const int hd = d_qk / num_heads;
     const float* base = qk + b * seqlen * 2 * d_qk + (int64_t)h * hd;
     double* nu_out = nu + pair * seqlen;                                                // [B, H, L]
+    constexpr int kScanT = (J <= 2) ? 16 : (J == 4 ? 8 : 4);   // tokens per round (register budget)
+    constexpr int kGrp = 64 / kScanT;                         // lanes that end up sharing one token's sum
+    const int64_t t_begin = (int64_t)chunk * kScanChunk;
+    const int64_t t_end = (t_begin + kScanChunk < seqlen) ? t_begin + kScanChunk : seqlen;
     double state[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) state[j] = 0.0;
-    double keep = 0.0;
-    for (int64_t t = 0; t < seqlen; ++t) {
-        const float* row = base + t * 2 * d_qk;
-        double part = 0.0;
+    for (int c = 0; c < chunk; ++c) {                       // carry-in: sums of the preceding chunks
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int d = lane + 64 * j;
-            if (d < hd) {
-                state[j] += (double)row[d_qk + d];
-                part = fma((double)row[d], state[j], part);
+            if (d < hd) state[j] += csum[(pair * nchunks + c) * hd + d];
+        }
+    }
+    for (int64_t t0 = t_begin; t0 < t_end; t0 += kScanT) {
+        float qv[kScanT][J], kv[kScanT][J];
+#pragma unroll
+        for (int u = 0; u < kScanT; ++u) {
+            const int64_t t = (t0 + u < t_end) ? (t0 + u) : (t_end - 1);
+            const float* row = base + t * 2 * d_qk;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int d = lane + 64 * j;
+                qv[u][j] = (d < hd) ? row[d] : 0.0f;
+                kv[u][j] = (d < hd) ? row[d_qk + d] : 0.0f;
             }
         }
-        const double tot = wave_sum(part);
-        if ((t & 63) == lane) keep = tot;
-        if ((t & 63) == 63 || t == seqlen - 1) {
-            const int64_t t0 = t & ~(int64_t)63;
-            if (t0 + lane <= t) nu_out[t0 + lane] = keep;                               // coalesced 512-B store
+        double prod[kScanT];
+#pragma unroll
+        for (int u = 0; u < kScanT; ++u) {
+            double part = 0.0;
+            if (t0 + u < t_end) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    state[j] += (double)kv[u][j];
+                    part = fma((double)qv[u][j], state[j], part);
+                }
+            }
+            prod[u] = part;
         }
+        treduce_t<double, kScanT, 32>(prod, lane);
+        // value index = lane / kGrp (top bits of the lane), complete in all kGrp lanes of the group
+        const int64_t t = t0 + lane / kGrp;
+        if ((lane % kGrp) == 0 && t < t_end) nu_out[t] = prod[0];
     }
 }
 
@@ -262,8 +468,10 @@ size_t attn_workspace_bytes(int64_t batch, int64_t seqlen, int d_qk, int num_hea
     size_t qk = (size_t)chunk * seqlen * 2 * d_qk * sizeof(float);
     size_t nu = (size_t)chunk * num_heads * seqlen * sizeof(double);
     size_t m = (size_t)chunk * num_heads * seqlen * sizeof(float);
+    const int64_t nchunks = (seqlen + kScanChunk - 1) / kScanChunk;
+    size_t cs = (size_t)chunk * nchunks * d_qk * sizeof(double);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    return up(qk) + up(nu) + up(m);
+    return up(qk) + up(nu) + up(m) + up(cs);
 }
 
 int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_qk,
@@ -287,13 +495,26 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
     double* nu = reinterpret_cast<double*>(wsp + up((size_t)chunk * seqlen * 2 * d_qk * sizeof(float)));
     float* mrow = reinterpret_cast<float*>(reinterpret_cast<char*>(nu) +
                                            up((size_t)chunk * num_heads * seqlen * sizeof(double)));
+    double* csum = reinterpret_cast<double*>(reinterpret_cast<char*>(mrow) +
+                                             up((size_t)chunk * num_heads * seqlen * sizeof(float)));
+    const int nchunks = (int)((seqlen + kScanChunk - 1) / kScanChunk);
     const int n_cols = 2 * d_qk;
     for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
         const int64_t nb = (batch - b0 < chunk) ? (batch - b0) : chunk;
         const int64_t rows = nb * seqlen;
         const dim3 pgrid((unsigned)((rows + kBM - 1) / kBM), (unsigned)((n_cols + kBN - 1) / kBN));
         const float* xin = x + b0 * seqlen * d_model;
-        if (softmax)
+        const bool mfma_ok = (d_model % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                             ((reinterpret_cast<uintptr_t>(w_qk) & 15) == 0);
+        if (mfma_ok) {
+            const dim3 mgrid((unsigned)((rows + kMT - 1) / kMT), (unsigned)((n_cols + kMT - 1) / kMT));
+            if (softmax)
+                hipLaunchKernelGGL(qk_proj_mfma_kernel<false>, mgrid, dim3(256), 0, stream, xin, rows, d_model, w_qk,
+                                   b_qk, n_cols, qk);
+            else
+                hipLaunchKernelGGL(qk_proj_mfma_kernel<true>, mgrid, dim3(256), 0, stream, xin, rows, d_model, w_qk,
+                                   b_qk, n_cols, qk);
+        } else if (softmax)
             hipLaunchKernelGGL(qk_proj_kernel<false>, pgrid, dim3(256), 0, stream, xin, rows, d_model, w_qk, b_qk,
                                n_cols, qk);
         else
@@ -304,20 +525,18 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
             const dim3 sgrid((unsigned)((seqlen + kTT - 1) / kTT), (unsigned)num_heads, (unsigned)nb);
             hipLaunchKernelGGL(softmax_nu_kernel, sgrid, dim3(256), 0, stream, qk, seqlen, d_qk, num_heads, nu, mrow);
         } else {
-            const int64_t pairs = nb * num_heads;
-            const unsigned grid = (unsigned)((pairs + 3) / 4);
-            if (hd <= 64)
-                hipLaunchKernelGGL(linattn_scan_kernel<1>, dim3(grid), dim3(256), 0, stream, qk, nb, seqlen, d_qk,
-                                   num_heads, nu);
-            else if (hd <= 128)
-                hipLaunchKernelGGL(linattn_scan_kernel<2>, dim3(grid), dim3(256), 0, stream, qk, nb, seqlen, d_qk,
-                                   num_heads, nu);
-            else if (hd <= 256)
-                hipLaunchKernelGGL(linattn_scan_kernel<4>, dim3(grid), dim3(256), 0, stream, qk, nb, seqlen, d_qk,
-                                   num_heads, nu);
-            else
-                hipLaunchKernelGGL(linattn_scan_kernel<8>, dim3(grid), dim3(256), 0, stream, qk, nb, seqlen, d_qk,
-                                   num_heads, nu);
+            const int64_t tasks = nb * num_heads * nchunks;
+            const unsigned grid = (unsigned)((tasks + 3) / 4);
+#define EGS_SCAN_LAUNCH(JJ)                                                                                              \
+    hipLaunchKernelGGL(linattn_chunksum_kernel<JJ>, dim3(grid), dim3(256), 0, stream, qk, nb, seqlen, d_qk, num_heads,  \
+                       nchunks, csum);                                                                                   \
+    hipLaunchKernelGGL(linattn_scan_kernel<JJ>, dim3(grid), dim3(256), 0, stream, qk, nb, seqlen, d_qk, num_heads,      \
+                       nchunks, csum, nu);
+            if (hd <= 64) { EGS_SCAN_LAUNCH(1) }
+            else if (hd <= 128) { EGS_SCAN_LAUNCH(2) }
+            else if (hd <= 256) { EGS_SCAN_LAUNCH(4) }
+            else { EGS_SCAN_LAUNCH(8) }
+#undef EGS_SCAN_LAUNCH
         }
         EGS_LAUNCH_CHECK();
         const int64_t total = nb * (seqlen - 1) * num_heads;
