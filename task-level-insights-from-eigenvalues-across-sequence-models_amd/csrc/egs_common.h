@@ -75,20 +75,29 @@ __device__ __forceinline__ float wave_sum(float v) {
 // the consumer is a Householder reflector, which is insensitive to the last bit).
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
+#ifdef EGS_ONE_NEWTON
+    const double e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
+#else
+    // one cubically convergent step: r (1 + e + e^2), e = 1 - x r  (seed error 5e-8 -> < 1 ulp)
+    const double e = __builtin_fma(-x, r, 1.0);
+    const double p = __builtin_fma(e, e, e);
+    return __builtin_fma(r, p, r);
+#endif
 }
 
-// 1/sqrt(x) for normal positive x: hardware seed + two Newton steps.
+// 1/sqrt(x) for normal positive x: hardware seed + one cubically convergent step.
 __device__ __forceinline__ double fast_rsqrt(double x) {
     double r = __builtin_amdgcn_rsq(x);
-    double h = 0.5 * x;
-    double e = __builtin_fma(-h * r, r, 0.5);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-h * r, r, 0.5);
+#ifdef EGS_ONE_NEWTON
+    const double e = __builtin_fma(-0.5 * x * r, r, 0.5);
     return __builtin_fma(r, e, r);
+#else
+    // y (1 + e/2 + 3 e^2 / 8), e = 1 - x y^2
+    const double e = __builtin_fma(-x * r, r, 1.0);
+    const double p = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(r * e, p, r);
+#endif
 }
 
 }  // namespace egs
