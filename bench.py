@@ -166,15 +166,29 @@ def main():
     qr_flops = 10.0 * n ** 3 * chunk
     hs_flops = (10.0 / 3.0) * n ** 3 * chunk
     achieved_tf = qr_flops / (hq_avg * 1e-3) / 1e12
+    # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be read from
+    # inside the process; collected with rocprofv3 --pmc on this same command at the same launch size, 16384 matrices)
+    traffic = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if chunk == 16384 and n == 64:
+            traffic = tr["kernels"]["hqr_real_kernel"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {
         "bound": "mfma", "kernel": "hqr_real_kernel", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": None,
+        "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
         "note": "fp64 (vector = matrix peak); algorithmic 10 n^3 flops per matrix, %d matrices per launch" % chunk,
         "avg_launch_ms": hq_avg, "launches_timed": nlaunch,
         "hess_kernel": {"kernel": "hess_real_kernel", "avg_launch_ms": hs_avg,
                         "achieved_tflops": hs_flops / (hs_avg * 1e-3) / 1e12},
         "hbm_gbs_algorithmic": (n * n * 8 + 16 * n) * chunk / ((hq_avg + hs_avg) * 1e-3) / 1e9,
     }
+
+    # ---- HBM-bound kernels of the same path (north_star: >= 40 % of HBM peak on the scan kernels), timed live ----
+    secondary = None
+    if rank == 0 and world == 1:
+        secondary = stream_rooflines(ops, device)
 
     # ---- parity: GPU spectra vs the known spectrum and vs LAPACK on a sample ----
     info_bad = int((info != 0).sum().item())
@@ -197,7 +211,7 @@ def main():
                        "d_state": n, "matrices_per_gpu": nmat, "matrix_kind": args.matrices,
                        "parallelism": "matrix-sharded x%d, one all_gather of spectra" % world},
             "max_abs_dlambda_vs_lapack": d_lapack, "max_abs_dlambda_vs_known": d_known, "unconverged": info_bad,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "secondary_rooflines": secondary,
         }
         if cpu is not None:
             result["speedup_vs_cpu_1core"] = value / cpu["value"]
@@ -206,6 +220,48 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def stream_rooflines(ops, device):
+    """Achieved algorithmic HBM GB/s of K2 (Mamba-2 lambda_t, config C3) and achieved fp32 TFLOP/s of K3's MFMA
+    projection (linear attention, one GPU's shard of config C4), HIP events on the launch stream, median of 5."""
+    def med(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for r in range(reps):
+            fn()
+            ev[r + 1].record()
+        torch.cuda.synchronize()
+        return float(np.median([ev[r].elapsed_time(ev[r + 1]) for r in range(reps)]))
+
+    g = torch.Generator(device=device)
+    g.manual_seed(16)
+    out = []
+    B, L, D, nh = 1024, 2048, 128, 4
+    x = torch.randn((B, L, D), generator=g, device=device)
+    w = (torch.rand((nh, D), generator=g, device=device) * 2 - 1) / np.sqrt(D)
+    dtb = torch.randn(nh, generator=g, device=device)
+    alog = torch.log(torch.rand(nh, generator=g, device=device) * 15 + 1)
+    ms = med(lambda: ops.mamba2_lambda(x, w, None, dtb, alog))
+    gbs = B * L * (4 * D + 4 * nh) / ms / 1e6
+    out.append({"kernel": "mamba2_lambda_fast_kernel", "workload": "C3: Mamba-2 lambda_t, B=1024, L=2048, D=128, 4 heads",
+                "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "ms": ms, "algorithmic_bytes": B * L * (4 * D + 4 * nh)})
+    del x
+    B, L, D, dqk = 512, 4096, 128, 128
+    x = torch.randn((B, L, D), generator=g, device=device)
+    w = (torch.rand((2 * dqk, D), generator=g, device=device) * 2 - 1) / np.sqrt(D)
+    b = (torch.rand((2 * dqk,), generator=g, device=device) * 2 - 1) / np.sqrt(D)
+    ms = med(lambda: ops.linattn_eta(x, w, b, dqk, 1), reps=3)
+    tf = B * L * 2.0 * D * 2 * dqk / ms / 1e9
+    out.append({"kernel": "qk_proj_mfma_kernel + linattn_chunksum/scan + eta_finalize",
+                "workload": "C4 / 8 GPUs: linear attention eta, B=512, L=4096, D=128, d_qk=128, H=1",
+                "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "ms": ms,
+                "note": "fp32 MFMA (= fp32 vector peak); whole op incl. the fp64 scan",
+                "hbm_gbs_algorithmic": B * L * (4 * D + 8) / ms / 1e6})
+    return out
 
 
 def cpu_baseline(a, budget_s, O):
