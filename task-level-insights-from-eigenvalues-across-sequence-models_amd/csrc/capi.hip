@@ -37,8 +37,8 @@ int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, con
 int threshold_hist_launch(const void*, int, int, int64_t, int64_t, int64_t, const double*, int, double*, hipStream_t);
 size_t eig_real_lds_workspace_bytes(int64_t, int);
 int eig_real_lds_launch(const double*, int64_t, int, int, int64_t, double*, int32_t*, void*, size_t, hipStream_t);
-int hess_real_launch(const double*, int64_t, int, int, int64_t, double*, hipStream_t);
-int hqr_real_launch(const double*, int64_t, int, double*, int32_t*, hipStream_t);
+int hess_real_launch(const double*, int64_t, int, int, int64_t, double*, int32_t*, hipStream_t);
+int hqr_real_launch(const double*, int64_t, int, double*, int32_t*, int, hipStream_t);
 size_t eig_cplx_workspace_bytes(int64_t, int);
 int eig_cplx_launch(const void*, bool, int64_t, int, int, int64_t, double*, int32_t*, void*, size_t, hipStream_t);
 
@@ -128,7 +128,7 @@ int egs_hessenberg_batched(const double* a, int64_t nmat, int n, int lda, int64_
     EGS_ARG(lda >= n, 4);
     EGS_ARG(stride >= (int64_t)(n - 1) * lda + n || nmat == 1, 5);
     EGS_ARG(h != nullptr, 6);
-    return hess_real_launch(a, nmat, n, lda, stride, h, as_stream(stream));
+    return hess_real_launch(a, nmat, n, lda, stride, h, nullptr, as_stream(stream));   // no scaling: h ~ a exactly
 }
 
 int egs_hseqr_batched(const double* h, int64_t nmat, int n, double* w, int32_t* info, egs_stream_t stream) {
@@ -138,7 +138,7 @@ int egs_hseqr_batched(const double* h, int64_t nmat, int n, double* w, int32_t* 
     EGS_ARG(h != nullptr, 1);
     EGS_ARG(w != nullptr, 4);
     EGS_ARG(info != nullptr, 5);
-    return hqr_real_launch(h, nmat, n, w, info, as_stream(stream));
+    return hqr_real_launch(h, nmat, n, w, info, 0, as_stream(stream));
 }
 
 int egs_mamba2_lambda(const float* x, int64_t ntok, int d_model, int64_t ldx, const float* w_dt, const float* b_dt,

@@ -91,6 +91,8 @@ __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __res
 #define HM(i, j) H[(int64_t)(i) * ldh + (j)]
 
     // ---- load ----
+    if (tid == 0) s_idx = 0;
+    __syncthreads();
     {
         const double* src = a + mat * stride * (INREAL ? 1 : 2);
         for (int idx = tid; idx < n * n; idx += kCThreads) {
@@ -99,9 +101,17 @@ __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __res
             if (INREAL) v = {src[(int64_t)i * lda + j], 0.0};
             else v = {src[2 * ((int64_t)i * lda + j)], src[2 * ((int64_t)i * lda + j) + 1]};
             HM(i, j) = v;
+            if (!(fabs(v.re) <= 1.7976931348623157e308) || !(fabs(v.im) <= 1.7976931348623157e308)) s_idx = 1;
         }
     }
     __syncthreads();
+    if (s_idx != 0) {                    // NaN / Inf input: an error like numpy.linalg.eigvals, not a spectrum
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        double* wbad = w + mat * 2 * (int64_t)n;
+        for (int j = tid; j < 2 * n; j += kCThreads) wbad[j] = qnan;
+        if (tid == 0) info_out[mat] = n;
+        return;
+    }
 
     // ---- phase 1: Hessenberg reduction ----
     for (int k = 0; k < n - 2; ++k) {

@@ -33,6 +33,7 @@ struct MatViewT {
 // Hessenberg reduction (unblocked, xGEHD2-style), one wave per matrix, full n x ld layout in LDS.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kHessLd = 65;            // odd leading dimension: row and column sweeps conflict-free
+constexpr int kNonFinite = -2147483647;   // scale-slot sentinel: the input matrix holds NaN / Inf
 constexpr int kHessWaves = 4;          // matrices per workgroup (4 x 33,792 B = 135 KB LDS)
 constexpr int kHessStride = kWave * kHessLd + 2 * kWave;   // matrix + Householder vector v + update vector y, in doubles
 // the Householder entry v_i is wave-uniform: either a broadcast LDS read or two v_readlane of the lane-held copy
@@ -43,7 +44,8 @@ constexpr int kHessStride = kWave * kHessLd + 2 * kWave;   // matrix + Household
 #endif
 
 __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
-    const double* __restrict__ a, int64_t nmat, int n, int lda, int64_t stride, double* __restrict__ hout) {
+    const double* __restrict__ a, int64_t nmat, int n, int lda, int64_t stride, double* __restrict__ hout,
+    int32_t* __restrict__ scale_exp) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -57,6 +59,8 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     const bool inr = lane < n;
 
     // coalesced load: consecutive lanes read consecutive elements of a row; 8 rows in flight
+    double amax = 0.0;
+    bool finite = true;
     {
         int i = 0;
         for (; i + 8 <= n; i += 8) {
@@ -64,13 +68,37 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
 #pragma unroll
             for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(i + u) * lda + lc];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 8; ++u) {
                 if (inr) s[(i + u) * kHessLd + lane] = t[u];
+                amax = fmax(amax, fabs(t[u]));
+                finite = finite && (fabs(t[u]) <= 1.7976931348623157e308);   // false for NaN and Inf
+            }
         }
-        for (; i < n; ++i)
-            if (inr) s[i * kHessLd + lane] = src[(int64_t)i * lda + lane];
+        for (; i < n; ++i) {
+            const double t = src[(int64_t)i * lda + lc];
+            if (inr) s[i * kHessLd + lane] = t;
+            amax = fmax(amax, fabs(t));
+            finite = finite && (fabs(t) <= 1.7976931348623157e308);
+        }
     }
     wave_lds_sync();
+    // xGEEV-style scaling: matrices whose largest entry is outside [1e-140, 1e140] are scaled by a power of two so
+    // that the unscaled reflector arithmetic (squares of entries) cannot overflow / underflow; the QR stage multiplies
+    // the eigenvalues back.  The exponent travels in the info slot between the two kernels.
+    if (scale_exp != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
+        int e = 0;
+        if (__ballot(!finite) != 0ULL) e = kNonFinite;           // NaN / Inf input: the QR stage reports failure
+        else if (amax > 0.0 && (amax < 1e-140 || amax > 1e140)) e = ilogb(amax);
+        if (e != 0 && e != kNonFinite) {
+            const double sc = scalbn(1.0, -e);
+            for (int i = 0; i < n; ++i)
+                if (inr) s[i * kHessLd + lane] *= sc;
+            wave_lds_sync();
+        }
+        if (lane == 0) scale_exp[mat] = e;
+    }
 
     for (int k = 0; k < n - 2; ++k) {
         // lane i holds x_i = A(i,k), i > k
@@ -347,7 +375,7 @@ __device__ __forceinline__ void qr_step2(const V& H, int k, int l, int i, int la
 
 template <class V>
 __device__ void hqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
-                         int32_t* __restrict__ info_out) {
+                         int32_t* __restrict__ info_out, const double rescale) {
     const double ulp = 2.220446049250313e-16;                      // dlamch('P')
     const double safmin = 2.2250738585072014e-308;
     const double smlnum = safmin * ((double)n / ulp);
@@ -500,7 +528,7 @@ __device__ void hqr_wave(const V H, const int n, const int lane, double* __restr
             break;
         }
         if (l == i) {
-            const double wr = H.at(i, i);
+            const double wr = H.at(i, i) * rescale;
             if (lane == 0) {
                 w_out[2 * i] = wr;
                 w_out[2 * i + 1] = 0.0;
@@ -509,10 +537,10 @@ __device__ void hqr_wave(const V H, const int n, const int lane, double* __restr
             double rt1r, rt1i, rt2r, rt2i;
             lanv2_eig(H.at(i - 1, i - 1), H.at(i - 1, i), H.at(i, i - 1), H.at(i, i), rt1r, rt1i, rt2r, rt2i);
             if (lane == 0) {
-                w_out[2 * (i - 1)] = rt1r;
-                w_out[2 * (i - 1) + 1] = rt1i;
-                w_out[2 * i] = rt2r;
-                w_out[2 * i + 1] = rt2i;
+                w_out[2 * (i - 1)] = rt1r * rescale;
+                w_out[2 * (i - 1) + 1] = rt1i * rescale;
+                w_out[2 * i] = rt2r * rescale;
+                w_out[2 * i + 1] = rt2i * rescale;
             }
         }
         kdefl = 0;
@@ -538,18 +566,18 @@ __host__ __device__ inline int hqr_pair_ld(int n) {
 
 template <class V>
 __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ src, int n, int lane,
-                                        double* __restrict__ wo, int32_t* __restrict__ info) {
+                                        double* __restrict__ wo, int32_t* __restrict__ info, double rescale) {
     // load the Hessenberg part plus the two extra sub-diagonals a bulge may touch (zeros)
     for (int i = 0; i < n; ++i) {
         if (lane < n && i <= lane + 3) H.at(i, lane) = (i <= lane + 1) ? src[(int64_t)i * n + lane] : 0.0;
     }
     wave_lds_sync();
-    hqr_wave(H, n, lane, wo, info);
+    hqr_wave(H, n, lane, wo, info, rescale);
 }
 
 __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
                                                        double* __restrict__ w, int32_t* __restrict__ info,
-                                                       int waves_per_block) {
+                                                       int waves_per_block, int scaled) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -559,12 +587,20 @@ __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict_
     double* base = smem + (size_t)(wave >> 1) * ((size_t)n * ldp);
     const double* src = hin + mat * (int64_t)n * n;
     double* wo = w + mat * 2 * (int64_t)n;
+    // when the Hessenberg stage scaled the matrix, info[mat] carries the power-of-two exponent to undo
+    if (scaled && info[mat] == kNonFinite) {     // like numpy.linalg.eigvals, non-finite input is an error, not a spectrum
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int j = lane; j < 2 * n; j += kWave) wo[j] = qnan;
+        if (lane == 0) info[mat] = n;
+        return;
+    }
+    const double rescale = scaled ? scalbn(1.0, info[mat]) : 1.0;
     if (n == 64) {
-        if ((wave & 1) == 0) hqr_run(MatViewT<71, false>{base + 7, ldp}, src, n, lane, wo, info + mat);
-        else hqr_run(MatViewT<71, true>{base, ldp}, src, n, lane, wo, info + mat);
+        if ((wave & 1) == 0) hqr_run(MatViewT<71, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
+        else hqr_run(MatViewT<71, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
     } else {
-        if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat);
-        else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat);
+        if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
+        else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
     }
 }
 
@@ -584,19 +620,20 @@ static int set_lds_attrs() {
     return 0;
 }
 
-int hess_real_launch(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h, hipStream_t stream) {
+int hess_real_launch(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h, int32_t* scale_exp,
+                     hipStream_t stream) {
     if (nmat == 0 || n == 0) return 0;
     int st = set_lds_attrs();
     if (st) return st;
     const size_t hess_lds = (size_t)kHessWaves * kHessStride * sizeof(double);
     const unsigned gh = (unsigned)((nmat + kHessWaves - 1) / kHessWaves);
     hipLaunchKernelGGL(hess_real_kernel, dim3(gh), dim3(kHessWaves * kWave), hess_lds, stream, a, nmat, n, lda, stride,
-                       h);
+                       h, scale_exp);
     EGS_LAUNCH_CHECK();
     return 0;
 }
 
-int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* info, hipStream_t stream) {
+int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* info, int scaled, hipStream_t stream) {
     if (nmat == 0 || n == 0) return 0;
     int st = set_lds_attrs();
     if (st) return st;
@@ -615,7 +652,7 @@ int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* in
     const size_t hqr_lds = pairs * pair_bytes;
     const unsigned gq = (unsigned)((nmat + hqr_waves - 1) / hqr_waves);
     hipLaunchKernelGGL(hqr_real_kernel, dim3(gq), dim3(hqr_waves * kWave), hqr_lds, stream, h, nmat, n, w, info,
-                       hqr_waves);
+                       hqr_waves, scaled);
     EGS_LAUNCH_CHECK();
     return 0;
 }
@@ -633,9 +670,9 @@ int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t s
     double* hws = static_cast<double*>(workspace);
     for (int64_t m0 = 0; m0 < nmat; m0 += chunk) {
         const int64_t cnt = (nmat - m0 < chunk) ? (nmat - m0) : chunk;
-        int st = hess_real_launch(a + m0 * stride, cnt, n, lda, stride, hws, stream);
+        int st = hess_real_launch(a + m0 * stride, cnt, n, lda, stride, hws, info + m0, stream);
         if (st) return st;
-        st = hqr_real_launch(hws, cnt, n, w + m0 * 2 * (int64_t)n, info + m0, stream);
+        st = hqr_real_launch(hws, cnt, n, w + m0 * 2 * (int64_t)n, info + m0, 1, stream);
         if (st) return st;
     }
     return 0;

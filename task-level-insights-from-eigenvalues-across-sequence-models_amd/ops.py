@@ -63,6 +63,9 @@ def eig_general_batched(a, workspace=None):
         raise ValueError(f"expected [..., n, n], got {tuple(a.shape)}")
     n = a.shape[-1]
     batch_shape = a.shape[:-2]
+    if n == 0 or a.numel() == 0:
+        return (torch.empty(tuple(batch_shape) + (n,), dtype=torch.complex128, device=a.device),
+                torch.zeros(tuple(batch_shape), dtype=torch.int32, device=a.device))
     a3 = a.reshape(-1, n, n)
     if not a3.is_contiguous():
         a3 = a3.contiguous()

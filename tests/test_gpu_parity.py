@@ -353,3 +353,61 @@ def test_threshold_hist_random_layouts(gpu_ops, shape):
     want32 = np.stack([m.sum(axis=1) / t_len * 100
                        for m in O.eig_oracle._bin_masks(flat.astype(np.float32).astype(np.float64), O.THRESHOLDS_RADIUS)])
     np.testing.assert_array_equal(f32.reshape(want32.shape), want32)
+
+
+# ---- robustness / degenerate shapes ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("scale", [1e-200, 1e-150, 1e150, 1e250])
+def test_eig_real_extreme_scaling(gpu_ops, scale):
+    """xGEEV-style scaling: entries far outside the range where squares are representable."""
+    rng = np.random.default_rng(21)
+    a, lam = known_spectrum_real(rng, 9, 24)
+    w, info = gpu_ops.eig_general_batched(dev(a * scale))
+    assert int(info.abs().sum()) == 0
+    assert O.max_abs_dlambda(w.cpu().numpy() / scale, lam) < 1e-9
+
+
+def test_eig_nan_matrix_is_isolated(gpu_ops):
+    """A NaN / Inf matrix must terminate (info > 0, NaN spectrum) without touching its batch neighbours."""
+    rng = np.random.default_rng(22)
+    a, lam = known_spectrum_real(rng, 10, 16)
+    a[3, 5, 7] = np.nan
+    a[6, 0, 0] = np.inf
+    w, info = gpu_ops.eig_general_batched(dev(a))
+    w, info = w.cpu().numpy(), info.cpu().numpy()
+    good = [i for i in range(10) if i not in (3, 6)]
+    assert np.all(info[good] == 0) and info[3] == 16 and info[6] == 16      # like LAPACK: all n outstanding
+    assert np.all(np.isnan(w[3].real)) and np.all(np.isnan(w[6].real))
+    assert O.max_abs_dlambda(w[good], lam[good]) < 1e-9
+    ac = a[good].astype(complex)
+    ac[1, 2, 2] = complex(np.nan, 0.0)
+    wc, infoc = gpu_ops.eig_general_batched(dev(ac))
+    infoc = infoc.cpu().numpy()
+    assert infoc[1] == 16 and np.all(np.delete(infoc, 1) == 0)
+    assert np.all(np.isnan(wc.cpu().numpy()[1].real))
+
+
+def test_degenerate_shapes(gpu_ops):
+    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device="cuda")
+    # sequences of length 1 have no ratio; empty batches are no-ops
+    assert gpu_ops.linattn_eta(z(3, 1, 8), z(8, 8), None, 4, 2).shape == (3, 0, 2)
+    assert gpu_ops.softmax_eta(z(0, 5, 8), z(8, 8), None, 4, 2).shape == (0, 4, 2)
+    assert gpu_ops.normattn_eta(z(2, 1, 8), z(2, 8), None, None, "exp", 2).shape == (2, 0, 2)
+    assert gpu_ops.mamba2_lambda(z(0, 7, 8), z(2, 8), None, z(2), z(2)).shape == (0, 7, 2)
+    one = gpu_ops.mamba2_lambda(torch.ones((1, 1, 128), device="cuda"), z(4, 128), None, z(4), z(4))
+    np.testing.assert_allclose(one.cpu().numpy(), np.exp(-np.log1p(np.exp(np.float32(0.0)))), rtol=1e-6)
+    pct = gpu_ops.threshold_hist(z(2, 0, 3, dt=torch.float64), O.THRESHOLDS_RADIUS, "value")
+    assert pct.shape == (7, 2, 3)          # T = 0: 0/0 like NumPy
+    assert gpu_ops.diag_ssm_lambda("lru", z(0, dt=torch.float64), z(0, dt=torch.float64)).shape == (0,)
+    w, info = gpu_ops.eig_general_batched(z(5, 0, 0, dt=torch.float64))
+    assert w.shape == (5, 0) and info.shape == (5,)
+
+
+def test_non_contiguous_and_strided_inputs(gpu_ops):
+    rng = np.random.default_rng(23)
+    a, lam = known_spectrum_real(rng, 6, 12)
+    big = torch.zeros((6, 12, 20), dtype=torch.float64, device="cuda")
+    big[:, :, 3:15] = dev(a)
+    w, info = gpu_ops.eig_general_batched(big[:, :, 3:15])            # non-contiguous view
+    assert int(info.abs().sum()) == 0 and O.max_abs_dlambda(w.cpu().numpy(), lam) < 1e-9
+    w, info = gpu_ops.eig_general_batched(dev(a).reshape(2, 3, 12, 12))   # leading batch dims
+    assert w.shape == (2, 3, 12) and info.shape == (2, 3)
