@@ -306,14 +306,13 @@ __device__ __forceinline__ void qr_step3(const V& H, double*& rowp, double*& col
     } else if (m_gt_l) {
         if (lane == 0) H.at(k, k - 1) = hkk1 * (1.0 - t1);
     }
-    {
-        const double sum = fma(u2, r2, fma(u1, r1, r0));
-        if (lane >= k && lane <= i) {
-            double* wp = V::kFast ? rowp : &H.at(k, lane);
-            wp[0] = fma(-sum, t1, r0);
-            wp[SR] = fma(-sum, t2, r1);
-            wp[2 * SR] = fma(-sum, t3, r2);
-        }
+    const double rsum = fma(u2, r2, fma(u1, r1, r0));
+    const double nr0 = fma(-rsum, t1, r0), nr1 = fma(-rsum, t2, r1), nr2 = fma(-rsum, t3, r2);
+    if (lane >= k && lane <= i) {
+        double* wp = V::kFast ? rowp : &H.at(k, lane);
+        wp[0] = nr0;
+        wp[SR] = nr1;
+        wp[2 * SR] = nr2;
     }
     wave_lds_sync();
     const int rmax = (k + 3 < i) ? k + 3 : i;             // column op: rows l..min(k+3, i)
@@ -322,6 +321,9 @@ __device__ __forceinline__ void qr_step3(const V& H, double*& rowp, double*& col
         c0 = colp[0];
         c1 = colp[SC];
         c2 = colp[2 * SC];
+        // keep the just-stored row values live across the column loads: otherwise the allocator lands the loads in
+        // the stores' source registers and the compiler has to drain the LDS queue (s_waitcnt) in between
+        asm volatile("" ::"v"(nr0), "v"(nr1), "v"(nr2));
     } else {
         const int rc = min(max(lane, l), rmax);
         c0 = H.at(rc, k);
