@@ -60,44 +60,70 @@ __global__ __launch_bounds__(256) void hist_count_kernel(const void* __restrict_
     const int64_t o = blockIdx.y;
     const int tpc = (inner >= 256) ? 1 : (int)(256 / inner);       // rows handled concurrently
     const int nthreads_used = (inner >= 256) ? 256 : (int)(tpc * inner);
-    if ((int)threadIdx.x >= nthreads_used) return;
+    const bool worker = (int)threadIdx.x < nthreads_used;
     const int64_t t_begin = (int64_t)blockIdx.x * rows_per_block;
     int64_t t_end = t_begin + rows_per_block;
     if (t_end > t_len) t_end = t_len;
     const int nb = ed.n + 1;
+    // per-workgroup counters: the threads of a workgroup that share a column meet in LDS first, so that only one
+    // global atomic per (bin, column, workgroup) reaches memory (same-address global atomics serialise)
+    __shared__ unsigned lcnt[kMaxEdges + 1][256];
     for (int64_t c0 = 0; c0 < inner; c0 += 256) {                  // one pass unless inner > 256
-        int64_t c;
-        int r0, rstep;
+        for (int idx = threadIdx.x; idx < (kMaxEdges + 1) * 256; idx += 256) (&lcnt[0][0])[idx] = 0u;
+        __syncthreads();
+        int64_t c = 0;
+        int r0 = 0, rstep = 1;
+        bool have = worker;
         if (inner >= 256) {
             c = c0 + threadIdx.x;
-            r0 = 0;
-            rstep = 1;
-            if (c >= inner) continue;
-        } else {
+            have = c < inner;
+        } else if (worker) {
             c = threadIdx.x % inner;
             r0 = (int)(threadIdx.x / inner);
             rstep = tpc;
         }
-        unsigned cnt[kMaxEdges + 1];
+        if (have) {
+            unsigned cnt[kMaxEdges + 1];
 #pragma unroll
-        for (int b = 0; b <= kMaxEdges; ++b) cnt[b] = 0;
-        for (int64_t t = t_begin + r0; t < t_end; t += rstep) {
-            const double v = load_transformed<DTYPE>(vals, (o * t_len + t) * inner + c, transform);
+            for (int b = 0; b <= kMaxEdges; ++b) cnt[b] = 0;
+            auto tally = [&](double v) {
 #pragma unroll
-            for (int b = 0; b <= kMaxEdges; ++b) {
-                if (b < nb) {
-                    bool in;
-                    if (b == 0) in = (v >= 0.0) && (v <= ed.e[0]);
-                    else if (b == nb - 1) in = v > ed.e[b - 1];
-                    else in = (v >= ed.e[b - 1]) && (v <= ed.e[b]);
-                    cnt[b] += in ? 1u : 0u;
+                for (int b = 0; b <= kMaxEdges; ++b) {
+                    if (b < nb) {
+                        bool in;
+                        if (b == 0) in = (v >= 0.0) && (v <= ed.e[0]);
+                        else if (b == nb - 1) in = v > ed.e[b - 1];
+                        else in = (v >= ed.e[b - 1]) && (v <= ed.e[b]);
+                        cnt[b] += in ? 1u : 0u;
+                    }
                 }
+            };
+            int64_t t = t_begin + r0;
+            for (; t + 3 * rstep < t_end; t += 4 * rstep) {        // four independent loads in flight per thread
+                const int64_t base = (o * t_len + t) * inner + c;
+                const double v0 = load_transformed<DTYPE>(vals, base, transform);
+                const double v1 = load_transformed<DTYPE>(vals, base + (int64_t)rstep * inner, transform);
+                const double v2 = load_transformed<DTYPE>(vals, base + 2 * (int64_t)rstep * inner, transform);
+                const double v3 = load_transformed<DTYPE>(vals, base + 3 * (int64_t)rstep * inner, transform);
+                tally(v0);
+                tally(v1);
+                tally(v2);
+                tally(v3);
             }
-        }
+            for (; t < t_end; t += rstep) tally(load_transformed<DTYPE>(vals, (o * t_len + t) * inner + c, transform));
+            const int cl = (int)(c - c0);
 #pragma unroll
-        for (int b = 0; b <= kMaxEdges; ++b)
-            if (b < nb && cnt[b]) atomicAdd(&counts[((int64_t)b * outer + o) * inner + c], (unsigned long long)cnt[b]);
-        if (inner < 256) break;
+            for (int b = 0; b <= kMaxEdges; ++b)
+                if (b < nb && cnt[b]) atomicAdd(&lcnt[b][cl], cnt[b]);
+        }
+        __syncthreads();
+        const int ncols = (inner - c0 < 256) ? (int)(inner - c0) : 256;
+        for (int idx = threadIdx.x; idx < nb * ncols; idx += 256) {
+            const int b = idx / ncols, cl = idx - b * ncols;
+            const unsigned v = lcnt[b][cl];
+            if (v) atomicAdd(&counts[((int64_t)b * outer + o) * inner + c0 + cl], (unsigned long long)v);
+        }
+        __syncthreads();
     }
 }
 
