@@ -11,6 +11,8 @@
 // The working copy of the matrix lives in LDS when it fits (n <= 96), otherwise in the caller's workspace
 // (L2 / Infinity-Cache resident: 1 MB per 256 x 256 matrix).  Subdiagonals are NOT kept real (LAPACK rescales
 // to keep them real; the general-complex reflector formulas below do not need that).
+#include <stdlib.h>
+
 #include "egs_common.h"
 
 namespace egs {
@@ -75,7 +77,9 @@ __device__ __forceinline__ T block_reduce_sum(T v, T* red) {
 }
 
 // INREAL: the input matrices are real fp64 (converted on load).  LDS: working copy in dynamic shared memory.
-template <bool INREAL, bool LDS>
+// HESS_ONLY (with LDS): stop after the Hessenberg reduction and write H densely to `work` for the wave-per-matrix QR
+// kernel of eig_cplx_lds.hip (n <= 64); info[mat] is set to 0 (or n for non-finite input).
+template <bool INREAL, bool LDS, bool HESS_ONLY>
 __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __restrict__ a, int n, int lda,
                                                              int64_t stride, double* __restrict__ w,
                                                              int32_t* __restrict__ info_out,
@@ -158,6 +162,16 @@ __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __res
             for (int i = k + 1; i < n; ++i) HM(i, j) = zsub(HM(i, j), zmul(vsh[i], tw));
         }
         __syncthreads();
+    }
+
+    if constexpr (HESS_ONLY) {
+        zc* dst = reinterpret_cast<zc*>(work) + mat * (int64_t)n * n;
+        for (int idx = tid; idx < n * n; idx += kCThreads) {
+            const int r = idx / n, c = idx - r * n;
+            dst[idx] = (r > c + 1) ? zc{0.0, 0.0} : HM(r, c);
+        }
+        if (tid == 0) info_out[mat] = 0;
+        return;
     }
 
     // ---- phase 2: single-shift QR, eigenvalues only ----
@@ -324,9 +338,12 @@ __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __res
 }
 
 constexpr int kCplxLdsMaxN = 96;
+constexpr int kCplxWaveMaxN = 64;     // wave-per-matrix QR (eig_cplx_lds.hip) below this order
+
+int zhqr_wave_launch(const double* h, int64_t nmat, int n, double* w, int32_t* info, hipStream_t stream);
 
 size_t eig_cplx_workspace_bytes(int64_t nmat, int n) {
-    if (n <= kCplxLdsMaxN) return 256;
+    if (n > kCplxWaveMaxN && n <= kCplxLdsMaxN) return 256;
     return (size_t)nmat * n * n * 2 * sizeof(double);
 }
 
@@ -338,7 +355,8 @@ int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, i
         return -4;
     }
     const bool lds = n <= kCplxLdsMaxN;
-    if (!lds && workspace_bytes < eig_cplx_workspace_bytes(nmat, n)) {
+    const bool wave_qr = n <= kCplxWaveMaxN && !getenv("EGS_CPLX_BLOCK_QR");
+    if ((!lds || wave_qr) && workspace_bytes < eig_cplx_workspace_bytes(nmat, n)) {
         set_error("workspace too small: %zu < %zu", workspace_bytes, eig_cplx_workspace_bytes(nmat, n));
         return -9;
     }
@@ -353,8 +371,13 @@ int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, i
         EGS_LAUNCH_CHECK();
         return 0;
     };
-    if (in_real) return lds ? launch(eig_cplx_kernel<true, true>) : launch(eig_cplx_kernel<true, false>);
-    return lds ? launch(eig_cplx_kernel<false, true>) : launch(eig_cplx_kernel<false, false>);
+    if (wave_qr) {
+        const int st = in_real ? launch(eig_cplx_kernel<true, true, true>) : launch(eig_cplx_kernel<false, true, true>);
+        if (st) return st;
+        return zhqr_wave_launch(wk, nmat, n, w, info, stream);
+    }
+    if (in_real) return lds ? launch(eig_cplx_kernel<true, true, false>) : launch(eig_cplx_kernel<true, false, false>);
+    return lds ? launch(eig_cplx_kernel<false, true, false>) : launch(eig_cplx_kernel<false, false, false>);
 }
 
 }  // namespace egs
