@@ -341,6 +341,8 @@ constexpr int kCplxLdsMaxN = 96;
 constexpr int kCplxWaveMaxN = 64;     // wave-per-matrix QR (eig_cplx_lds.hip) below this order
 
 int zhqr_wave_launch(const double* h, int64_t nmat, int n, double* w, int32_t* info, hipStream_t stream);
+int zhess64_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, int64_t stride, double* hout, double* w,
+                   int32_t* info, hipStream_t stream);
 
 size_t eig_cplx_workspace_bytes(int64_t nmat, int n) {
     if (n > kCplxWaveMaxN && n <= kCplxLdsMaxN) return 256;
@@ -372,7 +374,11 @@ int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, i
         return 0;
     };
     if (wave_qr) {
-        const int st = in_real ? launch(eig_cplx_kernel<true, true, true>) : launch(eig_cplx_kernel<false, true, true>);
+        int st;
+        if (getenv("EGS_CPLX_OLD_HESS"))
+            st = in_real ? launch(eig_cplx_kernel<true, true, true>) : launch(eig_cplx_kernel<false, true, true>);
+        else
+            st = zhess64_launch(a, in_real, nmat, n, lda, stride, wk, w, info, stream);
         if (st) return st;
         return zhqr_wave_launch(wk, nmat, n, w, info, stream);
     }

@@ -5,7 +5,7 @@
 // operation, lane = row for the column operation, two Hessenberg matrices packed into one n x (n+5) LDS array (one
 // stored in columns >= row+3, its partner transposed in columns <= row+2), bulge column forwarded through v_readlane,
 // deflation and start searches lane-parallel + ballot, no workgroup barrier anywhere.  The Hessenberg reduction itself
-// is done by eig_cplx_kernel<..., HESS_ONLY> (one workgroup per matrix, eig_cplx.hip) into the workspace.
+// is done by zhess64_kernel below (one workgroup of 4 waves per matrix) into the workspace.
 #include "egs_common.h"
 
 namespace egs {
@@ -77,6 +77,169 @@ __device__ __forceinline__ void zlarfg2_fast(zq alpha, zq x, double& beta, zq& v
     const double rd = fast_rcp(fmax(d2, tiny));
     const zq sc = {dr * rd, -alpha.im * rd};                      // 1 / (alpha - beta)
     v2 = qmul(x, sc);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Hessenberg reduction for n <= 64, one workgroup (4 waves) per matrix, matrix in LDS (ld = n+1: row and column
+// sweeps conflict-free for 16-byte elements).  Each reflector is applied from both sides as ONE rank-2 update
+//     H^H A H = A - w v^H - v y^H,   p = A v,  q^H = v^H A,  a2 = v^H p,  c = |tau|^2 a2 / 2,
+//     w = tau p - c v,   y^H = conj(tau) q^H - c v^H,
+// with the streamed index of both passes split over the 4 waves (partials combined through LDS in a fixed order, so
+// every wave holds bit-identical scalars).  Output: dense H (exact zeros below the subdiagonal) + info (0, or n for
+// NaN / Inf input together with a NaN spectrum, like numpy.linalg.eigvals' finiteness check).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kZH = 256;
+
+template <bool INREAL>
+__global__ __launch_bounds__(kZH) void zhess64_kernel(const double* __restrict__ a, int n, int lda, int64_t stride,
+                                                      double* __restrict__ hout, double* __restrict__ w,
+                                                      int32_t* __restrict__ info) {
+    extern __shared__ double dynz[];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t mat = blockIdx.x;
+    const int ldh = n + 1;
+    zq* H = reinterpret_cast<zq*>(dynz);
+    zq* vsh = H + (size_t)n * ldh;            // [64]
+    zq* ysh = vsh + 64;                       // [4 waves][64]  private y^H per wave
+    zq* part = ysh + 4 * 64;                  // [4 waves][p | q][64]
+#define ZH(i, j) H[(i) * ldh + (j)]
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    {
+        const double* src = a + mat * stride * (INREAL ? 1 : 2);
+        for (int idx = tid; idx < n * n; idx += kZH) {
+            const int i = idx / n, j = idx - i * n;
+            zq v;
+            if (INREAL) v = {src[(int64_t)i * lda + j], 0.0};
+            else v = {src[2 * ((int64_t)i * lda + j)], src[2 * ((int64_t)i * lda + j) + 1]};
+            ZH(i, j) = v;
+            if (!(fabs(v.re) <= 1.7976931348623157e308) || !(fabs(v.im) <= 1.7976931348623157e308)) s_bad = 1;
+        }
+    }
+    __syncthreads();
+    if (s_bad != 0) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        double* wbad = w + mat * 2 * (int64_t)n;
+        for (int j = tid; j < 2 * n; j += kZH) wbad[j] = qnan;
+        if (tid == 0) info[mat] = n;
+        return;
+    }
+    const int lc = (lane < n) ? lane : n - 1;
+    const bool inr = lane < n;
+    for (int k = 0; k < n - 2; ++k) {
+        // every wave reads column k (lane = row) and forms the reflector redundantly
+        const zq xi = (lane > k && inr) ? ZH(lane, k) : zq{0.0, 0.0};
+        const zq alpha = qbcast(xi, k + 1);
+        const double xnorm2 = wave_sum((lane > k + 1) ? fma(xi.re, xi.re, xi.im * xi.im) : 0.0);
+        const bool act = !(xnorm2 == 0.0 && alpha.im == 0.0);          // block-uniform
+        const double nrm = sqrt(fma(alpha.re, alpha.re, alpha.im * alpha.im) + xnorm2);
+        const double beta = act ? -copysign(nrm, alpha.re) : alpha.re;
+        const zq tau = act ? zq{(beta - alpha.re) / beta, -alpha.im / beta} : zq{0.0, 0.0};
+        const zq sc = act ? qdiv({1.0, 0.0}, {alpha.re - beta, alpha.im}) : zq{0.0, 0.0};
+        const zq v = !act ? zq{0.0, 0.0}
+                          : ((lane == k + 1) ? zq{1.0, 0.0} : ((lane > k + 1 && inr) ? qmul(xi, sc) : zq{0.0, 0.0}));
+        __syncthreads();                                   // every wave has read column k
+        if (wv == 0) {
+            vsh[lane] = v;
+            if (act && lane > k && inr) ZH(lane, k) = (lane == k + 1) ? zq{beta, 0.0} : zq{0.0, 0.0};
+        }
+        __syncthreads();
+        // pass 1: this wave's quarter of t = k+1..n-1;  p_i (lane = row i),  q_j = (v^H A)_j (lane = column j)
+        const int len = n - k - 1;
+        const int qlen = (len + 3) >> 2;
+        const int t0 = k + 1 + wv * qlen;
+        const int t1 = (t0 + qlen < n) ? t0 + qlen : n;
+        zq pp = {0.0, 0.0}, qq = {0.0, 0.0};
+        {
+            int t = t0;
+            for (; t + 4 <= t1; t += 4) {
+                zq ar[4], ac[4], vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ar[u] = ZH(lc, t + u);
+                    ac[u] = ZH(t + u, lc);
+                    vv[u] = vsh[t + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pp = qadd(pp, qmul(ar[u], vv[u]));
+                    qq = qadd(qq, qcmul(vv[u], ac[u]));
+                }
+            }
+            for (; t < t1; ++t) {
+                const zq vt = vsh[t];
+                pp = qadd(pp, qmul(ZH(lc, t), vt));
+                qq = qadd(qq, qcmul(vt, ZH(t, lc)));
+            }
+        }
+        part[(wv * 2 + 0) * 64 + lane] = pp;
+        part[(wv * 2 + 1) * 64 + lane] = qq;
+        __syncthreads();
+        zq p = {0.0, 0.0}, q = {0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            p = qadd(p, part[(x * 2 + 0) * 64 + lane]);
+            q = qadd(q, part[(x * 2 + 1) * 64 + lane]);
+        }
+        if (!inr) p = {0.0, 0.0};
+        if (!(lane > k && inr)) q = {0.0, 0.0};            // only columns j > k are updated
+        const zq vp = qcmul(v, p);                        // conj(v_i) p_i
+        const zq a2 = {wave_sum(vp.re), wave_sum(vp.im)};
+        const double t2 = 0.5 * fma(tau.re, tau.re, tau.im * tau.im);
+        const zq c = qscale(a2, t2);
+        const zq wi = qsub(qmul(tau, p), qmul(c, v));                              // w_i,   lane = row
+        ysh[wv * 64 + lane] = qsub(qcmul(tau, q), qmulc(c, v));                    // y^H_j, lane = column
+        wave_lds_sync();
+        // pass 2: this wave's quarter of the columns, lane = row:  A(i,j) -= w_i conj(v_j) + v_i y^H_j
+        {
+            int j = t0;
+            for (; j + 4 <= t1; j += 4) {
+                zq av[4], vv[4], yy[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    av[u] = ZH(lc, j + u);
+                    vv[u] = vsh[j + u];
+                    yy[u] = ysh[wv * 64 + j + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (inr) ZH(lane, j + u) = qsub(av[u], qadd(qmulc(wi, vv[u]), qmul(v, yy[u])));
+            }
+            for (; j < t1; ++j)
+                if (inr) ZH(lane, j) = qsub(ZH(lane, j), qadd(qmulc(wi, vsh[j]), qmul(v, ysh[wv * 64 + j])));
+        }
+        __syncthreads();
+    }
+    zq* dst = reinterpret_cast<zq*>(hout) + mat * (int64_t)n * n;
+    for (int idx = tid; idx < n * n; idx += kZH) {
+        const int r = idx / n, c = idx - r * n;
+        dst[idx] = (r > c + 1) ? zq{0.0, 0.0} : ZH(r, c);
+    }
+    if (tid == 0) info[mat] = 0;
+#undef ZH
+}
+
+int zhess64_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, int64_t stride, double* hout, double* w,
+                   int32_t* info, hipStream_t stream) {
+    if (nmat == 0 || n == 0) return 0;
+    const size_t dyn = ((size_t)n * (n + 1) + 64 + 4 * 64 + 8 * 64) * 2 * sizeof(double);
+    const double* ap = static_cast<const double*>(a);
+    if (in_real) {
+        if (dyn > 48 * 1024)
+            EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zhess64_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(zhess64_kernel<true>, dim3((unsigned)nmat), dim3(kZH), dyn, stream, ap, n, lda, stride, hout, w,
+                           info);
+    } else {
+        if (dyn > 48 * 1024)
+            EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zhess64_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(zhess64_kernel<false>, dim3((unsigned)nmat), dim3(kZH), dyn, stream, ap, n, lda, stride, hout,
+                           w, info);
+    }
+    EGS_LAUNCH_CHECK();
+    return 0;
 }
 
 template <class V>
