@@ -8,11 +8,10 @@
 //   phase 2: single-shift QR with the xLAHQR control flow (Ahues-Tisseur deflation test on |re|+|im|
 //            magnitudes, Wilkinson shift, exceptional shifts every 10 stalled iterations, start at two
 //            consecutive small subdiagonals); 2-element reflectors; eigenvalues only (active window only).
+// Orders n <= 64 take the wave-per-matrix kernels of eig_cplx_lds.hip instead (see eig_cplx_launch below).
 // The working copy of the matrix lives in LDS when it fits (n <= 96), otherwise in the caller's workspace
 // (L2 / Infinity-Cache resident: 1 MB per 256 x 256 matrix).  Subdiagonals are NOT kept real (LAPACK rescales
 // to keep them real; the general-complex reflector formulas below do not need that).
-#include <stdlib.h>
-
 #include "egs_common.h"
 
 namespace egs {
@@ -77,9 +76,7 @@ __device__ __forceinline__ T block_reduce_sum(T v, T* red) {
 }
 
 // INREAL: the input matrices are real fp64 (converted on load).  LDS: working copy in dynamic shared memory.
-// HESS_ONLY (with LDS): stop after the Hessenberg reduction and write H densely to `work` for the wave-per-matrix QR
-// kernel of eig_cplx_lds.hip (n <= 64); info[mat] is set to 0 (or n for non-finite input).
-template <bool INREAL, bool LDS, bool HESS_ONLY>
+template <bool INREAL, bool LDS>
 __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __restrict__ a, int n, int lda,
                                                              int64_t stride, double* __restrict__ w,
                                                              int32_t* __restrict__ info_out,
@@ -162,16 +159,6 @@ __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __res
             for (int i = k + 1; i < n; ++i) HM(i, j) = zsub(HM(i, j), zmul(vsh[i], tw));
         }
         __syncthreads();
-    }
-
-    if constexpr (HESS_ONLY) {
-        zc* dst = reinterpret_cast<zc*>(work) + mat * (int64_t)n * n;
-        for (int idx = tid; idx < n * n; idx += kCThreads) {
-            const int r = idx / n, c = idx - r * n;
-            dst[idx] = (r > c + 1) ? zc{0.0, 0.0} : HM(r, c);
-        }
-        if (tid == 0) info_out[mat] = 0;
-        return;
     }
 
     // ---- phase 2: single-shift QR, eigenvalues only ----
@@ -357,14 +344,19 @@ int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, i
         return -4;
     }
     const bool lds = n <= kCplxLdsMaxN;
-    const bool wave_qr = n <= kCplxWaveMaxN && !getenv("EGS_CPLX_BLOCK_QR");
+    const bool wave_qr = n <= kCplxWaveMaxN;
     if ((!lds || wave_qr) && workspace_bytes < eig_cplx_workspace_bytes(nmat, n)) {
         set_error("workspace too small: %zu < %zu", workspace_bytes, eig_cplx_workspace_bytes(nmat, n));
         return -9;
     }
+    double* wk = static_cast<double*>(workspace);
+    if (wave_qr) {        // n <= 64: workgroup-per-matrix Hessenberg + wave-per-matrix QR (eig_cplx_lds.hip)
+        const int st = zhess64_launch(a, in_real, nmat, n, lda, stride, wk, w, info, stream);
+        if (st) return st;
+        return zhqr_wave_launch(wk, nmat, n, w, info, stream);
+    }
     const size_t dyn = lds ? ((size_t)n * (n + 1) + n) * 2 * sizeof(double) : (size_t)n * 2 * sizeof(double);
     const double* ap = static_cast<const double*>(a);
-    double* wk = static_cast<double*>(workspace);
     auto launch = [&](auto kern) -> int {
         if (dyn > 48 * 1024)
             EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -373,17 +365,8 @@ int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, i
         EGS_LAUNCH_CHECK();
         return 0;
     };
-    if (wave_qr) {
-        int st;
-        if (getenv("EGS_CPLX_OLD_HESS"))
-            st = in_real ? launch(eig_cplx_kernel<true, true, true>) : launch(eig_cplx_kernel<false, true, true>);
-        else
-            st = zhess64_launch(a, in_real, nmat, n, lda, stride, wk, w, info, stream);
-        if (st) return st;
-        return zhqr_wave_launch(wk, nmat, n, w, info, stream);
-    }
-    if (in_real) return lds ? launch(eig_cplx_kernel<true, true, false>) : launch(eig_cplx_kernel<true, false, false>);
-    return lds ? launch(eig_cplx_kernel<false, true, false>) : launch(eig_cplx_kernel<false, false, false>);
+    if (in_real) return lds ? launch(eig_cplx_kernel<true, true>) : launch(eig_cplx_kernel<true, false>);
+    return lds ? launch(eig_cplx_kernel<false, true>) : launch(eig_cplx_kernel<false, false>);
 }
 
 }  // namespace egs

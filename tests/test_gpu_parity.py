@@ -232,7 +232,8 @@ def test_mamba2_matches_golden(gpu_ops, golden):
     np.testing.assert_allclose(lti.cpu().numpy()[..., None], g["lam_lti"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("d,nh,bias", [(128, 4, False), (512, 8, True), (20, 3, True), (130, 12, False), (7, 1, True)])
+@pytest.mark.parametrize("d,nh,bias", [(128, 4, False), (512, 8, True), (20, 3, True), (130, 12, False), (7, 1, True),
+                                       (64, 2, True), (256, 1, False), (1024, 5, True), (128, 8, False), (128, 9, False)])
 def test_mamba2_random_vs_oracle(gpu_ops, d, nh, bias):
     rng = np.random.default_rng(d * 31 + nh)
     bsz, seqlen = 3, 171
@@ -301,7 +302,8 @@ def test_softmax_attention_matches_golden(gpu_ops, golden, case, rtol):
     np.testing.assert_allclose(eta[finite], want[finite], rtol=rtol)
 
 
-@pytest.mark.parametrize("seqlen,d,d_qk,h", [(130, 24, 48, 2), (64, 16, 16, 1), (257, 40, 160, 1), (2, 8, 8, 4)])
+@pytest.mark.parametrize("seqlen,d,d_qk,h", [(130, 24, 48, 2), (64, 16, 16, 1), (257, 40, 160, 1), (2, 8, 8, 4),
+                                              (300, 18, 12, 3), (70, 36, 320, 1), (513, 128, 128, 1)])
 def test_attention_random_vs_oracle(gpu_ops, seqlen, d, d_qk, h):
     rng = np.random.default_rng(seqlen * 7 + d_qk)
     bsz = 3
