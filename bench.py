@@ -70,6 +70,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # best-effort all-core CPU figure: a separate process with a forked pool, started BEFORE this
+    # process initialises the GPU; 16 = the host-core share of one GPU on the bench box
+    cpu_multi = None
+    if world == 1 and not args.no_cpu and args.n == 64:
+        import subprocess
+        try:
+            procs = max(1, min(16, os.cpu_count() or 1))
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--procs", str(procs),
+                                  "--seconds", str(min(args.cpu_seconds, 10.0))], capture_output=True, text=True,
+                                 timeout=120)
+            cpu_multi = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as exc:            # the baseline is a courtesy figure; never fail the bench on it
+            cpu_multi = {"error": repr(exc)}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the eigenvalue-analysis path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -211,7 +224,8 @@ def main():
                        "d_state": n, "matrices_per_gpu": nmat, "matrix_kind": args.matrices,
                        "parallelism": "matrix-sharded x%d, one all_gather of spectra" % world},
             "max_abs_dlambda_vs_lapack": d_lapack, "max_abs_dlambda_vs_known": d_known, "unconverged": info_bad,
-            "roofline": roofline, "cpu_baseline": cpu, "secondary_rooflines": secondary,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_multi,
+            "secondary_rooflines": secondary,
         }
         if cpu is not None:
             result["speedup_vs_cpu_1core"] = value / cpu["value"]

@@ -9,6 +9,8 @@
 //                         sum exp(fp32(score - m_t)) in fp64) so that the reference's fp32 max-subtraction
 //                         (eval_eig.py:62-74) and its masking quirks Q4/Q5 are reproduced exactly.
 //   3. eta_finalize     : eta_t = nu_t / nu_{t+1} [* exp(m_t - m_{t+1})], nu == 0 -> 2e-23 (linear, Q6).
+#include <stdlib.h>
+
 #include "egs_common.h"
 
 namespace egs {
@@ -460,6 +462,10 @@ static int64_t attn_chunk(int64_t batch, int64_t seqlen, int d_qk) {
     if (chunk < 1) chunk = 1;
     if (chunk > batch) chunk = batch;
     if (chunk > 32768) chunk = 32768;          // softmax grid.z and the nu/m scratch stay bounded
+    if (const char* e = getenv("EGS_ATTN_CHUNK")) {          // test hook: force several batch chunks
+        const int64_t v = atoll(e);
+        if (v >= 1 && v < chunk) chunk = v;
+    }
     return chunk;
 }
 

@@ -413,3 +413,22 @@ def test_non_contiguous_and_strided_inputs(gpu_ops):
     assert int(info.abs().sum()) == 0 and O.max_abs_dlambda(w.cpu().numpy(), lam) < 1e-9
     w, info = gpu_ops.eig_general_batched(dev(a).reshape(2, 3, 12, 12))   # leading batch dims
     assert w.shape == (2, 3, 12) and info.shape == (2, 3)
+
+
+def test_chunked_execution_paths(gpu_ops, monkeypatch):
+    """Batches larger than the scratch space are processed in chunks: dense solver (explicit small workspace) and the
+    attention kernels (chunk size forced through the EGS_ATTN_CHUNK test hook)."""
+    rng = np.random.default_rng(31)
+    a, lam = known_spectrum_real(rng, 11, 16)
+    small_ws = torch.empty(3 * 16 * 16 * 8, dtype=torch.uint8, device="cuda")        # room for 3 of the 11 matrices
+    w, info = gpu_ops.eig_general_batched(dev(a), workspace=small_ws)
+    assert int(info.abs().sum()) == 0 and O.max_abs_dlambda(w.cpu().numpy(), lam) < 1e-9
+    bsz, seqlen, d, d_qk, h = 5, 70, 16, 16, 2
+    x = rng.standard_normal((bsz, seqlen, d)).astype(np.float32)
+    wq = (rng.standard_normal((2 * d_qk + d, d)) / np.sqrt(d)).astype(np.float32)
+    bq = (rng.standard_normal(2 * d_qk + d) * 0.1).astype(np.float32)
+    monkeypatch.setenv("EGS_ATTN_CHUNK", "2")                                          # 3 chunks: 2 + 2 + 1 sequences
+    lin = gpu_ops.linattn_eta(dev(x), dev(wq[:2 * d_qk]), dev(bq[:2 * d_qk]), d_qk, h).cpu().numpy()
+    sm = gpu_ops.softmax_eta(dev(x), dev(wq[:2 * d_qk]), dev(bq[:2 * d_qk]), d_qk, h).cpu().numpy()
+    np.testing.assert_allclose(lin, O.eta_linear(x, wq, bq, d_qk, h, d)[..., 0], rtol=1e-5)
+    np.testing.assert_allclose(sm, O.eta_softmax(x, wq, bq, d_qk, h, d)[..., 0], rtol=5e-5)

@@ -166,3 +166,44 @@ def test_eval_eig_rejects_unknown_layer_like_the_reference(pkg):
     with pytest.raises(RuntimeError, match="rnn is not a valid model option"):
         pkg.eval_eig(args, {"batch_size": 8}, None, None, None, "x.pth", 0.0)
     assert "layer" not in args["model"]                  # the pop() side effect of eval_eig.py:479 is kept
+
+
+def test_wandb_artifact_branch_member_names(pkg, tmp_path, monkeypatch):
+    """The W&B branch of the artefact writer (eval_eig.py:752-806) with a recording stand-in for the wandb module:
+    same run / artifact names and the same twelve member names, including the reference's "pase" typo (quirk Q16)."""
+    import types
+    ev = sys.modules[pkg.__name__ + ".analysis.eval_eig"]
+    calls = {"files": []}
+
+    class FakeArtifact:
+        def __init__(self, name, type):
+            calls["artifact"] = (name, type)
+
+        def add_file(self, local_path, name):
+            assert os.path.exists(local_path)
+            calls["files"].append(name)
+
+        def save(self):
+            calls["saved"] = True
+
+    fake = types.ModuleType("wandb")
+    fake.init = lambda **kw: calls.setdefault("init", kw)
+    fake.Artifact = FakeArtifact
+    fake.finish = lambda: calls.setdefault("finished", True)
+    monkeypatch.setitem(sys.modules, "wandb", fake)
+    monkeypatch.chdir(tmp_path)
+    open("percentage_file.txt", "w").write("report")
+    args = {"model": {"hidden_dim": 128, "state_dim": 64, "num_layers": 2}, "train": {"lr": 0.01}, "dataset": {"name": "MQAR"},
+            "seed": 1919}
+    arrays = [np.zeros((2, 3))] * 6 + [0, 0, 0, 0]
+    ev._save_artifacts(args, {"batch_size": 8}, {"name": "run7", "entity": "e", "project": "p"}, args["dataset"],
+                       args["model"], args["train"], 0.98765, arrays)
+    stem = "MQARrun7-dmodel128-seed1919-num_layers2-dqk64-conv_dim0-lr0.01"
+    name = stem + "-perf0.988"
+    assert calls["artifact"] == ("eigen_values_" + stem, "dataset")
+    assert calls["init"]["name"] == "upload" + name and calls["init"]["job_type"] == "add-dataset"
+    assert calls["files"] == [p + name for p in
+                              ["eigen_values_", "eigen_values_init_", "percentage_", "percentage_init_", "percentage_phase_",
+                               "percentage_pase_init_", "percentage_mean_", "percentage_init_mean_", "percentage_std_",
+                               "percentage_init_std_", "percentage_file_", "used_config-"]]
+    assert calls.get("saved") and calls.get("finished")
