@@ -15,7 +15,8 @@
 
 namespace egs {
 
-__device__ __forceinline__ float elu1_f32(float v) { return ((v > 0.0f) ? v : expm1f(v)) + 1.0f; }
+// phi(v) = elu(v) + 1 (analysis/eval_eig.py:109-110); for v <= 0 that is exp(v)
+__device__ __forceinline__ float elu1_f32(float v) { return (v > 0.0f) ? v + 1.0f : __expf(v); }
 
 // ---------------------------------------------------------------------------------------------------
 // 1. projection GEMM  out[M, N] = act(x[M, D] . W[N, D]^T + b[N])     64x64 tile, 256 threads, 4x4 / thread
@@ -189,6 +190,142 @@ __global__ __launch_bounds__(256) void qk_proj_mfma_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 1c. MFMA projection, second generation: block tile 128 rows x 256 columns (= all q,k columns when d_qk = 128, so x
+// is streamed from HBM exactly once), waves 2 x 2 with 64 x 128 each = 2 x 4 MFMA tiles (128 accumulator VGPRs, 6 LDS
+// operand reads per 8 MFMAs).  W is consumed pre-transposed (Wt[D][N], a 128 KB one-off transpose into the workspace)
+// so that a K-stage of it is copied with conflict-free ds_write_b128; the x stage keeps its row-major shape with an odd
+// leading dimension (33), which makes the A-fragment read (lane = row) conflict-free as well.
+// ---------------------------------------------------------------------------------------------------
+__global__ void wt_transpose_kernel(const float* __restrict__ w, int n_cols, int d_model, float* __restrict__ wt) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // over wt[d][n]
+    if (idx >= n_cols * d_model) return;
+    const int d = idx / n_cols, nn = idx - d * n_cols;
+    wt[idx] = w[(int64_t)nn * d_model + d];
+}
+
+constexpr int kM2R = 128, kM2C = 256, kM2K = 32, kM2LdA = 33, kM2LdB = kM2C + 4;
+constexpr int kPatchLd = 36;   // 32 x 32 epilogue patch per wave, rows 16-B aligned
+
+template <bool PHI>
+__global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __restrict__ x, int64_t m_rows, int d_model,
+                                                               const float* __restrict__ wt, const float* __restrict__ bias,
+                                                               int n_cols, float* __restrict__ out) {
+    __shared__ float as[kM2R][kM2LdA];
+    __shared__ __attribute__((aligned(16))) float bs[kM2K][kM2LdB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int64_t row0 = (int64_t)blockIdx.x * kM2R;
+    const int col0 = blockIdx.y * kM2C;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // x stage: thread -> rows (tid>>3) + 32 e, k-quad (tid&7);  Wt stage: thread -> k rows (tid>>6) + 4 e, column quad (tid&63)
+    float4 xa0, xa1, xa2, xa3, wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7;
+    const int xr = tid >> 3, xq = tid & 7;
+    const int wk = tid >> 6, wq = tid & 63;
+#define EGS_XLOAD(XA, E, K0)                                                                              \
+    {                                                                                                     \
+        const int64_t gr_ = row0 + xr + 32 * (E);                                                         \
+        const int gk_ = (K0) + xq * 4;                                                                    \
+        const bool ok_ = gr_ < m_rows && gk_ < d_model;                                                   \
+        XA = *reinterpret_cast<const float4*>(x + (ok_ ? gr_ * d_model + gk_ : 0));                       \
+        if (!ok_) XA = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+    }
+#define EGS_WLOAD(WB, E, K0)                                                                              \
+    {                                                                                                     \
+        const int gk_ = (K0) + wk + 4 * (E);                                                              \
+        const int gc_ = col0 + wq * 4;                                                                    \
+        const bool ok_ = gk_ < d_model && gc_ < n_cols;                                                   \
+        WB = *reinterpret_cast<const float4*>(wt + (ok_ ? (int64_t)gk_ * n_cols + gc_ : 0));              \
+        if (!ok_) WB = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+    }
+#define EGS_STAGE_LOAD(K0)                                                                                         \
+    EGS_XLOAD(xa0, 0, K0) EGS_XLOAD(xa1, 1, K0) EGS_XLOAD(xa2, 2, K0) EGS_XLOAD(xa3, 3, K0)                        \
+    EGS_WLOAD(wb0, 0, K0) EGS_WLOAD(wb1, 1, K0) EGS_WLOAD(wb2, 2, K0) EGS_WLOAD(wb3, 3, K0)                        \
+    EGS_WLOAD(wb4, 4, K0) EGS_WLOAD(wb5, 5, K0) EGS_WLOAD(wb6, 6, K0) EGS_WLOAD(wb7, 7, K0)
+#define EGS_XSTORE(XA, E)                               \
+    {                                                   \
+        float* p_ = &as[xr + 32 * (E)][xq * 4];         \
+        p_[0] = XA.x;                                   \
+        p_[1] = XA.y;                                   \
+        p_[2] = XA.z;                                   \
+        p_[3] = XA.w;                                   \
+    }
+#define EGS_WSTORE(WB, E) *reinterpret_cast<float4*>(&bs[wk + 4 * (E)][wq * 4]) = WB;
+#define EGS_STAGE_STORE()                                                                 \
+    EGS_XSTORE(xa0, 0) EGS_XSTORE(xa1, 1) EGS_XSTORE(xa2, 2) EGS_XSTORE(xa3, 3)           \
+    EGS_WSTORE(wb0, 0) EGS_WSTORE(wb1, 1) EGS_WSTORE(wb2, 2) EGS_WSTORE(wb3, 3)           \
+    EGS_WSTORE(wb4, 4) EGS_WSTORE(wb5, 5) EGS_WSTORE(wb6, 6) EGS_WSTORE(wb7, 7)
+
+    EGS_STAGE_LOAD(0)
+    for (int k0 = 0; k0 < d_model; k0 += kM2K) {
+        __syncthreads();
+        EGS_STAGE_STORE()
+        __syncthreads();
+        if (k0 + kM2K < d_model) { EGS_STAGE_LOAD(k0 + kM2K) }
+#pragma unroll
+        for (int k2 = 0; k2 < kM2K / 2; ++k2) {
+            const int kk = 2 * k2 + kh;
+            const float a0 = as[wm * 64 + l31][kk];
+            const float a1 = as[wm * 64 + 32 + l31][kk];
+            const float b0 = bs[kk][wn * 128 + l31];
+            const float b1 = bs[kk][wn * 128 + 32 + l31];
+            const float b2 = bs[kk][wn * 128 + 64 + l31];
+            const float b3 = bs[kk][wn * 128 + 96 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[0][3], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
+        }
+    }
+    // Epilogue: bias + phi, then each 32x32 accumulator tile is transposed through a per-wave LDS patch so that the
+    // global stores are 16 B per lane (8 lanes cover one 128-B row segment) instead of 16 dword stores per tile.
+    __syncthreads();                                   // every wave is done with the operand stages
+    float* patch = &bs[0][0] + wave * (32 * kPatchLd);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int gc = col0 + wn * 128 + tn * 32 + l31;
+            const float bv = (bias && gc < n_cols) ? bias[gc] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[tm][tn][r] + bv;
+                if (PHI) v = (v > 0.0f) ? v + 1.0f : __expf(v);     // elu(v) + 1 == exp(v) for v <= 0
+                patch[((r & 3) + 8 * (r >> 2) + 4 * kh) * kPatchLd + l31] = v;
+            }
+            wave_lds_sync();
+            const int pr = lane >> 3, pc = (lane & 7) * 4;
+            const int gcol = col0 + wn * 128 + tn * 32 + pc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = pr + 8 * q;
+                const float4 v4 = *reinterpret_cast<const float4*>(&patch[rr * kPatchLd + pc]);
+                const int64_t gr = row0 + wm * 64 + tm * 32 + rr;
+                if (gr < m_rows && gcol < n_cols) *reinterpret_cast<float4*>(out + gr * n_cols + gcol) = v4;
+            }
+            wave_lds_sync();
+        }
+#undef EGS_XLOAD
+#undef EGS_WLOAD
+#undef EGS_STAGE_LOAD
+#undef EGS_XSTORE
+#undef EGS_WSTORE
+#undef EGS_STAGE_STORE
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 2a. linear attention scan: one wavefront per (b, h); lane d holds the running sum of phi(k)[d] in fp64
 // ---------------------------------------------------------------------------------------------------
 // Transpose-reduce over the 64 lanes (see stream_kernels.hip): CNT values per lane in, lane l ends with the complete
@@ -247,7 +384,8 @@ __global__ __launch_bounds__(256) void linattn_chunksum_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int d = lane + 64 * j;
-                kv[u][j] = (d < hd && t + u < t_end) ? base[tt * 2 * d_qk + (d < hd ? d : 0)] : 0.0f;
+                const float kk = base[tt * 2 * d_qk + (d < hd ? d : hd - 1)];      // always-valid address
+                kv[u][j] = (d < hd && t + u < t_end) ? kk : 0.0f;
             }
         }
 #pragma unroll
@@ -291,6 +429,8 @@ __global__ __launch_bounds__(256) void linattn_scan_kernel(const float* __restri
         }
     }
     for (int64_t t0 = t_begin; t0 < t_end; t0 += kScanT) {
+        // all 2*J*kScanT loads of the round are issued back to back from always-valid addresses (clamped token and
+        // lane); out-of-range lanes / tokens are zeroed by value afterwards, so nothing serialises on a branch
         float qv[kScanT][J], kv[kScanT][J];
 #pragma unroll
         for (int u = 0; u < kScanT; ++u) {
@@ -299,10 +439,19 @@ __global__ __launch_bounds__(256) void linattn_scan_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int d = lane + 64 * j;
-                qv[u][j] = (d < hd) ? row[d] : 0.0f;
-                kv[u][j] = (d < hd) ? row[d_qk + d] : 0.0f;
+                const int dc = (d < hd) ? d : hd - 1;
+                qv[u][j] = row[dc];
+                kv[u][j] = row[d_qk + dc];
             }
         }
+#pragma unroll
+        for (int u = 0; u < kScanT; ++u)
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (lane + 64 * j >= hd) {
+                    qv[u][j] = 0.0f;
+                    kv[u][j] = 0.0f;
+                }
         double prod[kScanT];
 #pragma unroll
         for (int u = 0; u < kScanT; ++u) {
@@ -456,6 +605,8 @@ __global__ void eta_finalize_kernel(const double* __restrict__ nu, const float* 
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
+constexpr int kMaxDModelWt = 4096;   // hidden sizes up to this take the pre-transposed-W MFMA kernel
+
 static int64_t attn_chunk(int64_t batch, int64_t seqlen, int d_qk) {
     const int64_t per_seq = seqlen * 2 * (int64_t)d_qk * 4;
     int64_t chunk = ((int64_t)1 << 31) / (per_seq > 0 ? per_seq : 1);
@@ -476,8 +627,9 @@ size_t attn_workspace_bytes(int64_t batch, int64_t seqlen, int d_qk, int num_hea
     size_t m = (size_t)chunk * num_heads * seqlen * sizeof(float);
     const int64_t nchunks = (seqlen + kScanChunk - 1) / kScanChunk;
     size_t cs = (size_t)chunk * nchunks * d_qk * sizeof(double);
+    size_t wt = (size_t)2 * d_qk * kMaxDModelWt * sizeof(float);      // transposed q,k rows of Wqkv
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    return up(qk) + up(nu) + up(m) + up(cs);
+    return up(qk) + up(nu) + up(m) + up(cs) + up(wt);
 }
 
 int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_qk,
@@ -504,15 +656,32 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
     double* csum = reinterpret_cast<double*>(reinterpret_cast<char*>(mrow) +
                                              up((size_t)chunk * num_heads * seqlen * sizeof(float)));
     const int nchunks = (int)((seqlen + kScanChunk - 1) / kScanChunk);
+    float* wt = reinterpret_cast<float*>(reinterpret_cast<char*>(csum) +
+                                         up((size_t)chunk * nchunks * d_qk * sizeof(double)));
     const int n_cols = 2 * d_qk;
+    const bool mfma_ok = (d_model % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(w_qk) & 15) == 0);
+    const bool mfma2_ok = mfma_ok && (n_cols % 4 == 0) && d_model <= kMaxDModelWt && !getenv("EGS_PROJ_V1");
+    if (mfma2_ok) {
+        const int tot = n_cols * d_model;
+        hipLaunchKernelGGL(wt_transpose_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w_qk, n_cols,
+                           d_model, wt);
+        EGS_LAUNCH_CHECK();
+    }
     for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
         const int64_t nb = (batch - b0 < chunk) ? (batch - b0) : chunk;
         const int64_t rows = nb * seqlen;
         const dim3 pgrid((unsigned)((rows + kBM - 1) / kBM), (unsigned)((n_cols + kBN - 1) / kBN));
         const float* xin = x + b0 * seqlen * d_model;
-        const bool mfma_ok = (d_model % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                             ((reinterpret_cast<uintptr_t>(w_qk) & 15) == 0);
-        if (mfma_ok) {
+        if (mfma2_ok) {
+            const dim3 mgrid((unsigned)((rows + kM2R - 1) / kM2R), (unsigned)((n_cols + kM2C - 1) / kM2C));
+            if (softmax)
+                hipLaunchKernelGGL(qk_proj_mfma2_kernel<false>, mgrid, dim3(256), 0, stream, xin, rows, d_model, wt, b_qk,
+                                   n_cols, qk);
+            else
+                hipLaunchKernelGGL(qk_proj_mfma2_kernel<true>, mgrid, dim3(256), 0, stream, xin, rows, d_model, wt, b_qk,
+                                   n_cols, qk);
+        } else if (mfma_ok) {
             const dim3 mgrid((unsigned)((rows + kMT - 1) / kMT), (unsigned)((n_cols + kMT - 1) / kMT));
             if (softmax)
                 hipLaunchKernelGGL(qk_proj_mfma_kernel<false>, mgrid, dim3(256), 0, stream, xin, rows, d_model, w_qk,

@@ -411,13 +411,22 @@ __device__ void zhqr_wave(const V H, const int n, const int lane, double* __rest
 template <class V>
 __device__ __forceinline__ void zhqr_run(const V H, const double* __restrict__ src, int n, int lane,
                                          double* __restrict__ wo, int32_t* __restrict__ info) {
-    // Hessenberg part plus the one extra sub-diagonal a single-shift bulge touches
-    for (int i = 0; i < n; ++i) {
-        if (lane < n && i <= lane + 2) {
-            zq v = {0.0, 0.0};
-            if (i <= lane + 1) v = {src[2 * ((int64_t)i * n + lane)], src[2 * ((int64_t)i * n + lane) + 1]};
-            H.at(i, lane) = v;
-        }
+    // Hessenberg part plus the one extra sub-diagonal a single-shift bulge touches; 8 rows of 16-byte global loads in
+    // flight at a time from always-valid addresses (clamped lane), zeroed / dropped by value afterwards
+    const int lcl = (lane < n) ? lane : n - 1;
+    const zq* srcz = reinterpret_cast<const zq*>(src);
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        zq t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = srcz[(int64_t)(i + u) * n + lcl];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (lane < n && i + u <= lane + 2) H.at(i + u, lane) = (i + u <= lane + 1) ? t[u] : zq{0.0, 0.0};
+    }
+    for (; i < n; ++i) {
+        const zq t = srcz[(int64_t)i * n + lcl];
+        if (lane < n && i <= lane + 2) H.at(i, lane) = (i <= lane + 1) ? t : zq{0.0, 0.0};
     }
     wave_lds_sync();
     zhqr_wave(H, n, lane, wo, info);

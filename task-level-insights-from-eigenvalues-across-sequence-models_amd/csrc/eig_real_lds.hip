@@ -569,9 +569,21 @@ __host__ __device__ inline int hqr_pair_ld(int n) {
 template <class V>
 __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ src, int n, int lane,
                                         double* __restrict__ wo, int32_t* __restrict__ info, double rescale) {
-    // load the Hessenberg part plus the two extra sub-diagonals a bulge may touch (zeros)
-    for (int i = 0; i < n; ++i) {
-        if (lane < n && i <= lane + 3) H.at(i, lane) = (i <= lane + 1) ? src[(int64_t)i * n + lane] : 0.0;
+    // load the Hessenberg part plus the two extra sub-diagonals a bulge may touch (zeros); 8 rows of global loads in
+    // flight at a time, always from valid addresses (clamped lane), zeroed / dropped by value afterwards
+    const int lcl = (lane < n) ? lane : n - 1;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(i + u) * n + lcl];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (lane < n && i + u <= lane + 3) H.at(i + u, lane) = (i + u <= lane + 1) ? t[u] : 0.0;
+    }
+    for (; i < n; ++i) {
+        const double t = src[(int64_t)i * n + lcl];
+        if (lane < n && i <= lane + 3) H.at(i, lane) = (i <= lane + 1) ? t : 0.0;
     }
     wave_lds_sync();
     hqr_wave(H, n, lane, wo, info, rescale);
