@@ -510,13 +510,28 @@ __global__ __launch_bounds__(256) void softmax_nu_kernel(const float* __restrict
             for (int d0 = 0; d0 < hd; d0 += kDK) {
                 __syncthreads();
                 // stage q[t0.., d0..] and k[s0.., d0..] transposed to [d][row]: 4096 elements each, 16 / thread
-                for (int e = 0; e < 16; ++e) {
-                    const int idx = tid + e * 256;
-                    const int r = idx >> 6, dd = idx & 63;
-                    const bool dok = (d0 + dd) < hd;
-                    const int64_t tq = t0 + r, sk = s0 + r;
-                    qs[dd][r] = (dok && tq < seqlen) ? qbase[tq * 2 * d_qk + d0 + dd] : 0.0f;
-                    ks[dd][r] = (dok && sk < seqlen) ? kbase[sk * 2 * d_qk + d0 + dd] : 0.0f;
+                {
+                    // 32 global loads per thread issued back to back from always-valid (clamped) addresses, then
+                    // zeroed by value and written to LDS -- a per-element branch would serialise them
+                    float qv[16], kv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int idx = tid + e * 256;
+                        const int r = idx >> 6, dd = idx & 63;
+                        const int dc = (d0 + dd < hd) ? d0 + dd : hd - 1;
+                        const int64_t tq = (t0 + r < seqlen) ? t0 + r : seqlen - 1;
+                        const int64_t sk = (s0 + r < seqlen) ? s0 + r : seqlen - 1;
+                        qv[e] = qbase[tq * 2 * d_qk + dc];
+                        kv[e] = kbase[sk * 2 * d_qk + dc];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int idx = tid + e * 256;
+                        const int r = idx >> 6, dd = idx & 63;
+                        const bool dok = (d0 + dd) < hd;
+                        qs[dd][r] = (dok && t0 + r < seqlen) ? qv[e] : 0.0f;
+                        ks[dd][r] = (dok && s0 + r < seqlen) ? kv[e] : 0.0f;
+                    }
                 }
                 __syncthreads();
 #pragma unroll 8

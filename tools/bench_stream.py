@@ -30,7 +30,7 @@ def timeit(fn, reps=5, warm=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--which", default="k2,norm,k3,hist")
+    ap.add_argument("--which", default="k2,norm,k3,k4,hist")
     ap.add_argument("--scale", type=float, default=1.0, help="batch scale factor")
     args = ap.parse_args()
     ops = importlib.import_module(PKG).ops
@@ -67,6 +67,15 @@ def main():
         flops = B * L * 2.0 * D * 2 * dqk
         out["k3_linattn"] = {"ms": ms, "GBs": byts / ms / 1e6, "bytes": byts, "proj_TFLOPs": flops / ms / 1e9,
                              "eta_per_s": B * (L - 1) * H / ms * 1e3}
+        del x
+    if "k4" in which:          # softmax attention at the reference's MQAR scale: B=64, L=512, D=128, d_qk=128, H=1
+        B, L, D, dqk, H = 64, 512, 128, 128, 1
+        x = torch.randn((B, L, D), generator=g, device=dev)
+        w = (torch.rand((2 * dqk, D), generator=g, device=dev) * 2 - 1) / np.sqrt(D)
+        b = (torch.rand((2 * dqk,), generator=g, device=dev) * 2 - 1) / np.sqrt(D)
+        ms = timeit(lambda: ops.softmax_eta(x, w, b, dqk, H), reps=3, warm=1)
+        flops = 2.0 * B * H * (L * L / 2) * (dqk // H) * 2       # two passes over the causal half
+        out["k4_softmax"] = {"ms": ms, "score_TFLOPs": flops / ms / 1e9, "eta_per_s": B * (L - 1) * H / ms * 1e3}
         del x
     if "hist" in which:
         B, T, H, Ly = 4096, 4095, 1, 2
