@@ -297,6 +297,91 @@ __global__ __launch_bounds__(256) void mamba2_lambda_fast_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Norm-attention fast path: same streaming skeleton as mamba2_lambda_fast_kernel, with the ratio n_{t+1}/n_t formed
+// inside the wave.  Every wave iteration covers T = TPW*U consecutive tokens and advances by T-1, i.e. consecutive
+// iterations overlap by one token (1/T extra traffic) so that each ratio's two operands are always in the same
+// iteration: after the transpose-reduce the owner of (token u, head h) finds (token u+1, head h) NH*OWN lanes up.
+// ---------------------------------------------------------------------------------------------------
+template <int G, int C, int NH>
+__global__ __launch_bounds__(256) void normattn_fast_kernel(const float* __restrict__ x, int64_t ntok, int64_t ldx,
+                                                            const float* __restrict__ w, int nh_real,
+                                                            const float* __restrict__ b_n, const float* __restrict__ offset,
+                                                            int norm_fn, int64_t seqlen, double* __restrict__ eta) {
+    constexpr int D = 4 * G * C;
+    constexpr int TPW = 64 / G;
+    constexpr int U = (G / NH) < 4 ? (G / NH) : 4;
+    constexpr int V = U * NH;
+    constexpr int OWN = G / V;
+    constexpr int T = TPW * U;                        // tokens per iteration; T-1 ratios are emitted
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int grp = lane / G;
+    float4 wr[NH][C];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            wr[h][c] = (h < nh_real) ? *reinterpret_cast<const float4*>(w + (int64_t)h * D + (c * G + gl) * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int idx = gl / OWN;
+    const int my_u = idx / NH, my_h = idx % NH;
+    const int my_slot = grp * U + my_u;               // position of this lane's token inside the iteration
+    const bool owner = (gl % OWN) == 0 && my_h < nh_real;
+    float bias_h = 0.f;
+    if (my_h < nh_real) bias_h = (b_n ? b_n[my_h] : 0.f) + (offset ? offset[my_h] : 0.f);
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t t0 = wave_id * (T - 1); t0 + 1 < ntok; t0 += nwaves * (T - 1)) {
+        float4 xv[U][C];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t tok = t0 + grp * U + u;
+            const float* xr = x + (tok < ntok ? tok : ntok - 1) * ldx;
+#pragma unroll
+            for (int c = 0; c < C; ++c) xv[u][c] = *reinterpret_cast<const float4*>(xr + (c * G + gl) * 4);
+        }
+        float v[V];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    acc = fmaf(xv[u][c].x, wr[h][c].x, acc);
+                    acc = fmaf(xv[u][c].y, wr[h][c].y, acc);
+                    acc = fmaf(xv[u][c].z, wr[h][c].z, acc);
+                    acc = fmaf(xv[u][c].w, wr[h][c].w, acc);
+                }
+                v[u * NH + h] = acc;
+            }
+        treduce<V, G / 2>(v, gl);
+        // n = exp(-norm_fn(z + b + offset)) in fp32 (analysis/eval_eig.py:161-163)
+        const float z = v[0] + bias_h;
+        float f;
+        switch (norm_fn) {
+            case EGS_NORM_EXP: f = expf(z); break;
+            case EGS_NORM_ELU: f = elu_f32(z); break;
+            case EGS_NORM_SOFTPLUS: f = softplus_f32(z); break;
+            default: f = sigmoid_f32(z); break;
+        }
+        const float n_me = expf(-f);
+        const float n_next = __shfl_down(n_me, NH * OWN, 64);      // owner of (next token, same head)
+        const int64_t tok = t0 + my_slot;
+        if (owner && my_slot < T - 1 && tok + 1 < ntok) {
+            const int64_t b = tok / seqlen;
+            const int64_t t = tok - b * seqlen;
+            if (t < seqlen - 1) {
+                double n0 = (double)n_me, n1 = (double)n_next;     // :165-169, exact zeros -> 2e-23 (Q6)
+                if (n0 == 0.0) n0 = 2e-23;
+                if (n1 == 0.0) n1 = 2e-23;
+                eta[(b * (seqlen - 1) + t) * nh_real + my_h] = n1 / n0;
+            }
+        }
+    }
+}
+
 __global__ void mamba2_lti_kernel(const float* __restrict__ a_param, const float* __restrict__ beta, int nh,
                                   int64_t ntok, float* __restrict__ out) {
     // exp(beta * -softplus(A)) broadcast over tokens (analysis/eval_eig.py:194-199)
@@ -460,12 +545,44 @@ int mamba2_lambda_launch(const float* x, int64_t ntok, int d_model, int64_t ldx,
     return skinny_launch(false, x, ntok, d_model, ldx, w_dt, nheads, mp, np, stream);
 }
 
+template <int G, int C>
+static int normattn_fast_dispatch(int nh_pad, const float* x, int64_t ntok, int64_t ldx, const float* w, int nh,
+                                  const float* b_n, const float* offset, int norm_fn, int64_t seqlen, double* eta,
+                                  hipStream_t stream) {
+    constexpr int tok_per_block = 4 * (64 / G) * 4;
+    int64_t blocks = (ntok + tok_per_block - 1) / tok_per_block;
+    const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+    switch (nh_pad) {
+        case 1: hipLaunchKernelGGL((normattn_fast_kernel<G, C, 1>), dim3(grid), dim3(256), 0, stream, x, ntok, ldx, w, nh, b_n, offset, norm_fn, seqlen, eta); break;
+        case 2: hipLaunchKernelGGL((normattn_fast_kernel<G, C, 2>), dim3(grid), dim3(256), 0, stream, x, ntok, ldx, w, nh, b_n, offset, norm_fn, seqlen, eta); break;
+        case 4: hipLaunchKernelGGL((normattn_fast_kernel<G, C, 4>), dim3(grid), dim3(256), 0, stream, x, ntok, ldx, w, nh, b_n, offset, norm_fn, seqlen, eta); break;
+        default: hipLaunchKernelGGL((normattn_fast_kernel<G, C, 8>), dim3(grid), dim3(256), 0, stream, x, ntok, ldx, w, nh, b_n, offset, norm_fn, seqlen, eta); break;
+    }
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
 int normattn_eta_launch(const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_n,
                         const float* b_n, const float* offset, int norm_fn, int num_heads, double* eta,
                         hipStream_t stream) {
+    const int64_t ntok = batch * seqlen;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(w_n) & 15) == 0);
+    if (aligned && num_heads <= 8 && ntok >= 2) {
+        int nh_pad = 1;
+        while (nh_pad < num_heads) nh_pad <<= 1;
+        // T = TPW*U must be at least 2 for the overlapped iteration scheme: true for every (G, NH <= 8) below
+        switch (d_model) {
+            case 64: return normattn_fast_dispatch<16, 1>(nh_pad, x, ntok, d_model, w_n, num_heads, b_n, offset, norm_fn, seqlen, eta, stream);
+            case 128: return normattn_fast_dispatch<32, 1>(nh_pad, x, ntok, d_model, w_n, num_heads, b_n, offset, norm_fn, seqlen, eta, stream);
+            case 256: return normattn_fast_dispatch<64, 1>(nh_pad, x, ntok, d_model, w_n, num_heads, b_n, offset, norm_fn, seqlen, eta, stream);
+            case 512: return normattn_fast_dispatch<64, 2>(nh_pad, x, ntok, d_model, w_n, num_heads, b_n, offset, norm_fn, seqlen, eta, stream);
+            case 1024: return normattn_fast_dispatch<64, 4>(nh_pad, x, ntok, d_model, w_n, num_heads, b_n, offset, norm_fn, seqlen, eta, stream);
+            default: break;
+        }
+    }
     Mamba2Params mp{nullptr, nullptr, nullptr, nullptr};
     NormParams np{b_n, offset, norm_fn, seqlen, eta};
-    return skinny_launch(true, x, batch * seqlen, d_model, d_model, w_n, num_heads, mp, np, stream);
+    return skinny_launch(true, x, ntok, d_model, d_model, w_n, num_heads, mp, np, stream);
 }
 
 int mamba2_lti_launch(const float* a_param, const float* beta, int nheads, int64_t ntok, float* out,

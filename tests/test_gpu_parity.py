@@ -432,3 +432,20 @@ def test_chunked_execution_paths(gpu_ops, monkeypatch):
     sm = gpu_ops.softmax_eta(dev(x), dev(wq[:2 * d_qk]), dev(bq[:2 * d_qk]), d_qk, h).cpu().numpy()
     np.testing.assert_allclose(lin, O.eta_linear(x, wq, bq, d_qk, h, d)[..., 0], rtol=1e-5)
     np.testing.assert_allclose(sm, O.eta_softmax(x, wq, bq, d_qk, h, d)[..., 0], rtol=5e-5)
+
+
+@pytest.mark.parametrize("d,h,fn,use_off", [(128, 4, "softplus", True), (64, 2, "exp", False), (512, 8, "sigmoid", True),
+                                            (256, 3, "elu", False), (1024, 1, "softplus", False)])
+def test_norm_attention_fast_path_vs_oracle(gpu_ops, d, h, fn, use_off):
+    """Shapes served by normattn_fast_kernel (overlapped wave iterations); sequence ends fall inside iterations."""
+    rng = np.random.default_rng(d + h)
+    bsz, seqlen, d_qk = 3, 203, 8
+    x = rng.standard_normal((bsz, seqlen, d)).astype(np.float32)
+    w = (rng.standard_normal((d + 2 * d_qk + h, d)) / np.sqrt(d)).astype(np.float32)
+    b = (rng.standard_normal(d + 2 * d_qk + h) * 0.1).astype(np.float32)
+    off = rng.standard_normal(h).astype(np.float32) if use_off else None
+    lo = d + 2 * d_qk
+    got = gpu_ops.normattn_eta(dev(x), dev(w[lo:]), dev(b[lo:]), dev(off) if use_off else None, fn, h).cpu().numpy()
+    want = O.eta_norm(x, w, b, off, fn, d_qk, h, d)[..., 0]
+    assert got.shape == want.shape == (bsz, seqlen - 1, h)
+    np.testing.assert_allclose(got, want, rtol=3e-5)
