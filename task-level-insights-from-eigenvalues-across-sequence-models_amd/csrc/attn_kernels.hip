@@ -80,119 +80,17 @@ __global__ __launch_bounds__(256) void qk_proj_kernel(const float* __restrict__ 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// 1b. the same projection on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32: bit-for-bit a k-ordered fmaf
-// chain, MI355X_MICROARCH "FP32-input MFMA").  This is the one genuinely dense contraction of the attention path
-// (AI = d_qk flop/B, above the fp32 ridge), so it is the place where MFMA is the right tool.
-//   workgroup 256 threads = 4 waves as 2 x 2, block tile 128 x 128, each wave 64 x 64 = 2 x 2 MFMA tiles (64 acc VGPRs)
-//   K staged 32 at a time through LDS as [k][row] so that an operand fragment (lane l: row l&31, k l>>5) is a
-//   conflict-free ds_read_b32; next stage prefetched into registers while the current one is multiplied.
-// Operand / accumulator lane maps (cdna_hip_programming.md section 3):  A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
-//   D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
-// ---------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kMT = 128, kMK = 32, kMLd = kMT + 4;
-
-template <bool PHI>
-__global__ __launch_bounds__(256) void qk_proj_mfma_kernel(const float* __restrict__ x, int64_t m_rows, int d_model,
-                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                           int n_cols, float* __restrict__ out) {
-    __shared__ float as[kMK][kMLd];
-    __shared__ float bs[kMK][kMLd];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int64_t row0 = (int64_t)blockIdx.x * kMT;
-    const int col0 = blockIdx.y * kMT;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    // register prefetch buffers: thread t stages rows (t + 256 e) >> 3, k-quad (t & 7)
-    float4 xa0, xa1, xa2, xa3, wb0, wb1, wb2, wb3;
-    const int sr = tid >> 3, skq = tid & 7;
-#define EGS_GLOAD_ONE(XA, WB, E, K0)                                                                                 \
-    {                                                                                                                \
-        const int r_ = sr + 32 * (E);                                                                                \
-        const int gk_ = (K0) + skq * 4;                                                                              \
-        const int64_t gr_ = row0 + r_;                                                                               \
-        const int gc_ = col0 + r_;                                                                                   \
-        const bool okx_ = gr_ < m_rows && gk_ < d_model;                                                             \
-        const bool okw_ = gc_ < n_cols && gk_ < d_model;                                                             \
-        /* always load from a valid address, then zero by value (a pointer select would go through scratch) */      \
-        XA = *reinterpret_cast<const float4*>(x + (okx_ ? gr_ * d_model + gk_ : 0));                                 \
-        WB = *reinterpret_cast<const float4*>(w + (okw_ ? (int64_t)gc_ * d_model + gk_ : 0));                        \
-        if (!okx_) XA = make_float4(0.f, 0.f, 0.f, 0.f);                                                             \
-        if (!okw_) WB = make_float4(0.f, 0.f, 0.f, 0.f);                                                             \
-    }
-#define EGS_GLOAD(K0)                  \
-    EGS_GLOAD_ONE(xa0, wb0, 0, K0)     \
-    EGS_GLOAD_ONE(xa1, wb1, 1, K0)     \
-    EGS_GLOAD_ONE(xa2, wb2, 2, K0)     \
-    EGS_GLOAD_ONE(xa3, wb3, 3, K0)
-#define EGS_SSTORE_ONE(XA, WB, E)              \
-    {                                          \
-        const int r_ = sr + 32 * (E);          \
-        as[skq * 4 + 0][r_] = XA.x;            \
-        as[skq * 4 + 1][r_] = XA.y;            \
-        as[skq * 4 + 2][r_] = XA.z;            \
-        as[skq * 4 + 3][r_] = XA.w;            \
-        bs[skq * 4 + 0][r_] = WB.x;            \
-        bs[skq * 4 + 1][r_] = WB.y;            \
-        bs[skq * 4 + 2][r_] = WB.z;            \
-        bs[skq * 4 + 3][r_] = WB.w;            \
-    }
-#define EGS_SSTORE()               \
-    EGS_SSTORE_ONE(xa0, wb0, 0)    \
-    EGS_SSTORE_ONE(xa1, wb1, 1)    \
-    EGS_SSTORE_ONE(xa2, wb2, 2)    \
-    EGS_SSTORE_ONE(xa3, wb3, 3)
-    EGS_GLOAD(0)
-    for (int k0 = 0; k0 < d_model; k0 += kMK) {
-        __syncthreads();                     // everyone is done reading the previous stage
-        EGS_SSTORE()
-        __syncthreads();
-        if (k0 + kMK < d_model) { EGS_GLOAD(k0 + kMK) }
-        const int kh = lane >> 5, l31 = lane & 31;
-#pragma unroll
-        for (int k2 = 0; k2 < kMK / 2; ++k2) {
-            const float a0 = as[2 * k2 + kh][wm * 64 + l31];
-            const float a1 = as[2 * k2 + kh][wm * 64 + 32 + l31];
-            const float b0 = bs[2 * k2 + kh][wn * 64 + l31];
-            const float b1 = bs[2 * k2 + kh][wn * 64 + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    }
-    const int l31 = lane & 31, kh = lane >> 5;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int gc = col0 + wn * 64 + tn * 32 + l31;
-            const float bv = (bias && gc < n_cols) ? bias[gc] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t gr = row0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (gr < m_rows && gc < n_cols) {
-                    float v = acc[tm][tn][r] + bv;
-                    if (PHI) v = elu1_f32(v);
-                    out[gr * n_cols + gc] = v;
-                }
-            }
-        }
-}
 
 // ---------------------------------------------------------------------------------------------------
-// 1c. MFMA projection, second generation: block tile 128 rows x 256 columns (= all q,k columns when d_qk = 128, so x
-// is streamed from HBM exactly once), waves 2 x 2 with 64 x 128 each = 2 x 4 MFMA tiles (128 accumulator VGPRs, 6 LDS
-// operand reads per 8 MFMAs).  W is consumed pre-transposed (Wt[D][N], a 128 KB one-off transpose into the workspace)
+// 1b. the same projection on the matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32: bit-for-bit a k-ordered fmaf chain,
+// MI355X_MICROARCH "FP32-input MFMA").  This is the one genuinely dense contraction of the attention path (AI = d_qk
+// flop/B, above the fp32 ridge), so it is the place where MFMA is the right tool.  Operand / accumulator lane maps
+// (cdna_hip_programming.md section 3):  A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D: col = l&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// Block tile 128 rows x 256 columns (= all q,k columns when d_qk = 128, so x is streamed from HBM exactly once),
+// waves 2 x 2 with 64 x 128 each = 2 x 4 MFMA tiles (128 accumulator VGPRs, 6 LDS operand reads per 8 MFMAs); the
+// next K stage is prefetched into registers while the current one is multiplied.  W is consumed pre-transposed (Wt[D][N], a 128 KB one-off transpose into the workspace)
 // so that a K-stage of it is copied with conflict-free ds_write_b128; the x stage keeps its row-major shape with an odd
 // leading dimension (33), which makes the A-fragment read (lane = row) conflict-free as well.
 // ---------------------------------------------------------------------------------------------------
@@ -206,10 +104,19 @@ __global__ void wt_transpose_kernel(const float* __restrict__ w, int n_cols, int
 constexpr int kM2R = 128, kM2C = 256, kM2K = 32, kM2LdA = 33, kM2LdB = kM2C + 4;
 constexpr int kPatchLd = 36;   // 32 x 32 epilogue patch per wave, rows 16-B aligned
 
+// When `csum` is given (linear attention, seq_len a multiple of 32) the epilogue also accumulates, in fp64, the column
+// sums of phi(k) over each 32-row accumulator tile into csum[(b, h, chunk), d] -- the per-chunk carry-in sums the scan
+// needs -- so k is not read a second time for them (one 8-byte atomic per column and tile).
+struct ChunkSumArgs {
+    double* csum;          // [nseq * H * nchunks, hd] or null
+    int64_t seqlen;
+    int d_qk, num_heads, nchunks, chunk_tokens;
+};
+
 template <bool PHI>
 __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __restrict__ x, int64_t m_rows, int d_model,
                                                                const float* __restrict__ wt, const float* __restrict__ bias,
-                                                               int n_cols, float* __restrict__ out) {
+                                                               int n_cols, float* __restrict__ out, ChunkSumArgs cs) {
     __shared__ float as[kM2R][kM2LdA];
     __shared__ __attribute__((aligned(16))) float bs[kM2K][kM2LdB];
     const int tid = threadIdx.x;
@@ -299,11 +206,25 @@ __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __re
         for (int tn = 0; tn < 4; ++tn) {
             const int gc = col0 + wn * 128 + tn * 32 + l31;
             const float bv = (bias && gc < n_cols) ? bias[gc] : 0.0f;
+            double colsum = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[tm][tn][r] + bv;
                 if (PHI) v = (v > 0.0f) ? v + 1.0f : __expf(v);     // elu(v) + 1 == exp(v) for v <= 0
                 patch[((r & 3) + 8 * (r >> 2) + 4 * kh) * kPatchLd + l31] = v;
+                colsum += (double)v;
+            }
+            if (PHI && cs.csum != nullptr) {
+                colsum += __shfl_xor(colsum, 32, 64);              // the other 16 rows of this column
+                const int64_t grow = row0 + wm * 64 + tm * 32;      // first of the tile's 32 rows (one sequence, one chunk)
+                if (kh == 0 && gc >= cs.d_qk && gc < n_cols && grow < m_rows) {
+                    const int hd = cs.d_qk / cs.num_heads;
+                    const int kc = gc - cs.d_qk;
+                    const int64_t bseq = grow / cs.seqlen;
+                    const int chunk = (int)((grow - bseq * cs.seqlen) / cs.chunk_tokens);
+                    const int64_t task = (bseq * cs.num_heads + kc / hd) * cs.nchunks + chunk;
+                    atomicAdd(&cs.csum[task * hd + kc % hd], colsum);
+                }
             }
             wave_lds_sync();
             const int pr = lane >> 3, pc = (lane & 7) * 4;
@@ -676,7 +597,7 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
     const int n_cols = 2 * d_qk;
     const bool mfma_ok = (d_model % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(w_qk) & 15) == 0);
-    const bool mfma2_ok = mfma_ok && (n_cols % 4 == 0) && d_model <= kMaxDModelWt && !getenv("EGS_PROJ_V1");
+    const bool mfma2_ok = mfma_ok && (n_cols % 4 == 0) && d_model <= kMaxDModelWt;
     if (mfma2_ok) {
         const int tot = n_cols * d_model;
         hipLaunchKernelGGL(wt_transpose_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w_qk, n_cols,
@@ -688,22 +609,20 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
         const int64_t rows = nb * seqlen;
         const dim3 pgrid((unsigned)((rows + kBM - 1) / kBM), (unsigned)((n_cols + kBN - 1) / kBN));
         const float* xin = x + b0 * seqlen * d_model;
+        const bool fused_csum = mfma2_ok && !softmax && (seqlen % 32 == 0);
         if (mfma2_ok) {
             const dim3 mgrid((unsigned)((rows + kM2R - 1) / kM2R), (unsigned)((n_cols + kM2C - 1) / kM2C));
+            ChunkSumArgs cs{nullptr, seqlen, d_qk, num_heads, nchunks, kScanChunk};
+            if (fused_csum) {
+                cs.csum = csum;
+                EGS_HIP(hipMemsetAsync(csum, 0, (size_t)nb * nchunks * d_qk * sizeof(double), stream));
+            }
             if (softmax)
                 hipLaunchKernelGGL(qk_proj_mfma2_kernel<false>, mgrid, dim3(256), 0, stream, xin, rows, d_model, wt, b_qk,
-                                   n_cols, qk);
+                                   n_cols, qk, cs);
             else
                 hipLaunchKernelGGL(qk_proj_mfma2_kernel<true>, mgrid, dim3(256), 0, stream, xin, rows, d_model, wt, b_qk,
-                                   n_cols, qk);
-        } else if (mfma_ok) {
-            const dim3 mgrid((unsigned)((rows + kMT - 1) / kMT), (unsigned)((n_cols + kMT - 1) / kMT));
-            if (softmax)
-                hipLaunchKernelGGL(qk_proj_mfma_kernel<false>, mgrid, dim3(256), 0, stream, xin, rows, d_model, w_qk,
-                                   b_qk, n_cols, qk);
-            else
-                hipLaunchKernelGGL(qk_proj_mfma_kernel<true>, mgrid, dim3(256), 0, stream, xin, rows, d_model, w_qk,
-                                   b_qk, n_cols, qk);
+                                   n_cols, qk, cs);
         } else if (softmax)
             hipLaunchKernelGGL(qk_proj_kernel<false>, pgrid, dim3(256), 0, stream, xin, rows, d_model, w_qk, b_qk,
                                n_cols, qk);
@@ -718,8 +637,9 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
             const int64_t tasks = nb * num_heads * nchunks;
             const unsigned grid = (unsigned)((tasks + 3) / 4);
 #define EGS_SCAN_LAUNCH(JJ)                                                                                              \
-    hipLaunchKernelGGL(linattn_chunksum_kernel<JJ>, dim3(grid), dim3(256), 0, stream, qk, nb, seqlen, d_qk, num_heads,  \
-                       nchunks, csum);                                                                                   \
+    if (!fused_csum)                                                                                                     \
+        hipLaunchKernelGGL(linattn_chunksum_kernel<JJ>, dim3(grid), dim3(256), 0, stream, qk, nb, seqlen, d_qk,         \
+                           num_heads, nchunks, csum);                                                                    \
     hipLaunchKernelGGL(linattn_scan_kernel<JJ>, dim3(grid), dim3(256), 0, stream, qk, nb, seqlen, d_qk, num_heads,      \
                        nchunks, csum, nu);
             if (hd <= 64) { EGS_SCAN_LAUNCH(1) }

@@ -303,7 +303,8 @@ def test_softmax_attention_matches_golden(gpu_ops, golden, case, rtol):
 
 
 @pytest.mark.parametrize("seqlen,d,d_qk,h", [(130, 24, 48, 2), (64, 16, 16, 1), (257, 40, 160, 1), (2, 8, 8, 4),
-                                              (300, 18, 12, 3), (70, 36, 320, 1), (513, 128, 128, 1)])
+                                              (300, 18, 12, 3), (70, 36, 320, 1), (513, 128, 128, 1),
+                                              (320, 32, 64, 2), (768, 64, 128, 1)])
 def test_attention_random_vs_oracle(gpu_ops, seqlen, d, d_qk, h):
     rng = np.random.default_rng(seqlen * 7 + d_qk)
     bsz = 3
