@@ -22,8 +22,13 @@ def pytest_configure(config):
 
 
 def load_pkg():
-    """The product package (its directory name has hyphens, so it is imported via importlib)."""
-    return importlib.import_module(PKG_NAME)
+    """The product package (its directory name has hyphens, so it is imported via importlib).  The shared library is a
+    build artefact (git-ignored): compile it in-tree first if this checkout does not have it yet (hipcc cross-compiles
+    without a GPU; the same thing __graft_entry__.build() does)."""
+    pkg = importlib.import_module(PKG_NAME)
+    if not os.path.exists(pkg._capi.LIB_PATH):
+        pkg._capi.build()
+    return pkg
 
 
 @pytest.fixture(scope="session")
