@@ -207,3 +207,24 @@ def test_wandb_artifact_branch_member_names(pkg, tmp_path, monkeypatch):
                                "percentage_pase_init_", "percentage_mean_", "percentage_init_mean_", "percentage_std_",
                                "percentage_init_std_", "percentage_file_", "used_config-"]]
     assert calls.get("saved") and calls.get("finished")
+
+
+def test_bench_workload_generator_has_the_prescribed_spectrum():
+    """bench.py's C2 matrices: the returned eigenvalues are the true spectrum (checked with LAPACK on the CPU)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    g = torch.Generator()
+    g.manual_seed(64)
+    a, lam = bench.gen_known_spectrum(4, 64, g, torch.device("cpu"))
+    assert a.shape == (4, 64, 64) and a.dtype == torch.float64 and lam.shape == (4, 64)
+    assert O.max_abs_dlambda(np.linalg.eigvals(a.numpy()), lam.numpy()) < 1e-9
+    assert float(torch.max(torch.abs(lam))) < 1.0                      # S5-style: inside the unit disc
+
+
+def test_cpu_baseline_script_runs(tmp_path):
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--procs", "2", "--seconds", "0.3",
+                          "--block", "16"], capture_output=True, text=True, timeout=120)
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["cores"] == 2 and rec["value"] > 0 and rec["kind"] == "port"
