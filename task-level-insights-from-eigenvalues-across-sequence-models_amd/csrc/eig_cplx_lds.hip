@@ -93,7 +93,7 @@ constexpr int kZH = 256;
 template <bool INREAL>
 __global__ __launch_bounds__(kZH) void zhess64_kernel(const double* __restrict__ a, int n, int lda, int64_t stride,
                                                       double* __restrict__ hout, double* __restrict__ w,
-                                                      int32_t* __restrict__ info) {
+                                                      int32_t* __restrict__ info, int balance) {
     extern __shared__ double dynz[];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -127,6 +127,99 @@ __global__ __launch_bounds__(kZH) void zhess64_kernel(const double* __restrict__
     }
     const int lc = (lane < n) ? lane : n - 1;
     const bool inr = lane < n;
+    // ---- xGEBAL (permute + scale), by wave 0; same scheme as hess_real_kernel: isolated eigenvalues are moved to the
+    // ends of the diagonal (the reduction keeps their exact zeros, the QR stage deflates them at once) and the active
+    // block is equilibrated with power-of-two factors ----
+    if (balance && wv == 0) {
+#define ZNZ(i, j) (ZH(i, j).re != 0.0 || ZH(i, j).im != 0.0)
+        int k0 = 0, l0 = n - 1;
+        for (int guard = 0; guard < n; ++guard) {
+            bool rz = false;
+            if (lane <= l0) {
+                rz = true;
+                for (int j = 0; j <= l0; ++j)
+                    if (j != lane && ZNZ(lane, j)) rz = false;
+            }
+            const unsigned long long m = __ballot(rz);
+            if (m == 0ULL || l0 == 0) break;
+            const int r = uniform(63 - __builtin_clzll(m));
+            if (r != l0) {
+                if (lane <= l0) {
+                    const zq t = ZH(lane, r);
+                    ZH(lane, r) = ZH(lane, l0);
+                    ZH(lane, l0) = t;
+                }
+                wave_lds_sync();
+                if (inr) {
+                    const zq t = ZH(r, lane);
+                    ZH(r, lane) = ZH(l0, lane);
+                    ZH(l0, lane) = t;
+                }
+                wave_lds_sync();
+            }
+            --l0;
+        }
+        for (int guard = 0; guard < n; ++guard) {
+            bool cz = false;
+            if (lane >= k0 && lane <= l0) {
+                cz = true;
+                for (int i = k0; i <= l0; ++i)
+                    if (i != lane && ZNZ(i, lane)) cz = false;
+            }
+            const unsigned long long m = __ballot(cz);
+            if (m == 0ULL || k0 >= l0) break;
+            const int c = uniform(__builtin_ctzll(m));
+            if (c != k0) {
+                if (lane <= l0) {
+                    const zq t = ZH(lane, c);
+                    ZH(lane, c) = ZH(lane, k0);
+                    ZH(lane, k0) = t;
+                }
+                wave_lds_sync();
+                if (inr && lane >= k0) {
+                    const zq t = ZH(c, lane);
+                    ZH(c, lane) = ZH(k0, lane);
+                    ZH(k0, lane) = t;
+                }
+                wave_lds_sync();
+            }
+            ++k0;
+        }
+        for (int pass = 0; pass < 16; ++pass) {
+            double f = 1.0;
+            if (lane >= k0 && lane <= l0) {
+                double c = 0.0, r = 0.0;
+                for (int j = k0; j <= l0; ++j) {
+                    if (j != lane) {
+                        c += fabs(ZH(j, lane).re) + fabs(ZH(j, lane).im);
+                        r += fabs(ZH(lane, j).re) + fabs(ZH(lane, j).im);
+                    }
+                }
+                if (c != 0.0 && r != 0.0 && c < 1e300 && r < 1e300) {
+                    const double s0 = c + r;
+                    double g = r * 0.5;
+                    while (c < g) {
+                        f *= 2.0;
+                        c *= 4.0;
+                    }
+                    g = r * 2.0;
+                    while (c >= g) {
+                        f *= 0.5;
+                        c *= 0.25;
+                    }
+                    if ((c + r) / f >= 0.95 * s0) f = 1.0;
+                }
+            }
+            if (__ballot(f != 1.0) == 0ULL) break;
+            for (int r = 0; r < n; ++r) {
+                const double sc = f / bcast_lane(f, r);
+                if (inr) ZH(r, lane) = qscale(ZH(r, lane), sc);
+            }
+            wave_lds_sync();
+        }
+#undef ZNZ
+    }
+    __syncthreads();
     for (int k = 0; k < n - 2; ++k) {
         // every wave reads column k (lane = row) and forms the reflector redundantly
         const zq xi = (lane > k && inr) ? ZH(lane, k) : zq{0.0, 0.0};
@@ -225,18 +318,19 @@ int zhess64_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, in
     if (nmat == 0 || n == 0) return 0;
     const size_t dyn = ((size_t)n * (n + 1) + 64 + 4 * 64 + 8 * 64) * 2 * sizeof(double);
     const double* ap = static_cast<const double*>(a);
+    const int balance = getenv("EGS_NO_BALANCE") ? 0 : 1;
     if (in_real) {
         if (dyn > 48 * 1024)
             EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zhess64_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL(zhess64_kernel<true>, dim3((unsigned)nmat), dim3(kZH), dyn, stream, ap, n, lda, stride, hout, w,
-                           info);
+                           info, balance);
     } else {
         if (dyn > 48 * 1024)
             EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zhess64_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL(zhess64_kernel<false>, dim3((unsigned)nmat), dim3(kZH), dyn, stream, ap, n, lda, stride, hout,
-                           w, info);
+                           w, info, balance);
     }
     EGS_LAUNCH_CHECK();
     return 0;

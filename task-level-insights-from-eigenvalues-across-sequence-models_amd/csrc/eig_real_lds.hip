@@ -45,7 +45,7 @@ constexpr int kHessStride = kWave * kHessLd + 2 * kWave;   // matrix + Household
 
 __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     const double* __restrict__ a, int64_t nmat, int n, int lda, int64_t stride, double* __restrict__ hout,
-    int32_t* __restrict__ scale_exp) {
+    int32_t* __restrict__ scale_exp, int balance) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -98,6 +98,102 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
             wave_lds_sync();
         }
         if (lane == 0) scale_exp[mat] = e;
+    }
+
+    // ---- xGEBAL: permute rows/columns that isolate an eigenvalue to the ends, then scale the remaining block ----
+    // (what numpy.linalg.eigvals -> xGEEV does before the reduction).  Eigenvalues are invariant; the permuted matrix is
+    // block upper triangular with exact zeros that the reflectors below preserve (their tails are exactly zero
+    // there), so the QR stage deflates those eigenvalues immediately and exactly; the power-of-two diagonal scaling
+    // equilibrates row and column norms of the active block, which is what makes graded / badly scaled inputs accurate.
+    if (balance) {
+        int k0 = 0, l0 = n - 1;
+        for (int guard = 0; guard < n; ++guard) {                   // rows whose off-diagonal part in columns 0..l0 is zero
+            bool rz = false;
+            if (lane <= l0) {
+                rz = true;
+                for (int j = 0; j <= l0; ++j)
+                    if (j != lane && s[lane * kHessLd + j] != 0.0) rz = false;
+            }
+            const unsigned long long m = __ballot(rz);
+            if (m == 0ULL || l0 == 0) break;
+            const int r = uniform(63 - __builtin_clzll(m));
+            if (r != l0) {
+                if (lane <= l0) {                                   // swap columns r <-> l0 over rows 0..l0
+                    const double t = s[lane * kHessLd + r];
+                    s[lane * kHessLd + r] = s[lane * kHessLd + l0];
+                    s[lane * kHessLd + l0] = t;
+                }
+                wave_lds_sync();
+                if (inr) {                                          // swap rows r <-> l0 over all columns
+                    const double t = s[r * kHessLd + lane];
+                    s[r * kHessLd + lane] = s[l0 * kHessLd + lane];
+                    s[l0 * kHessLd + lane] = t;
+                }
+                wave_lds_sync();
+            }
+            --l0;
+        }
+        for (int guard = 0; guard < n; ++guard) {                   // columns whose off-diagonal part in rows k0..l0 is zero
+            bool cz = false;
+            if (lane >= k0 && lane <= l0) {
+                cz = true;
+                for (int i = k0; i <= l0; ++i)
+                    if (i != lane && s[i * kHessLd + lane] != 0.0) cz = false;
+            }
+            const unsigned long long m = __ballot(cz);
+            if (m == 0ULL || k0 >= l0) break;
+            const int c = uniform(__builtin_ctzll(m));
+            if (c != k0) {
+                if (lane <= l0) {
+                    const double t = s[lane * kHessLd + c];
+                    s[lane * kHessLd + c] = s[lane * kHessLd + k0];
+                    s[lane * kHessLd + k0] = t;
+                }
+                wave_lds_sync();
+                if (inr && lane >= k0) {
+                    const double t = s[c * kHessLd + lane];
+                    s[c * kHessLd + lane] = s[k0 * kHessLd + lane];
+                    s[k0 * kHessLd + lane] = t;
+                }
+                wave_lds_sync();
+            }
+            ++k0;
+        }
+        // scaling of the block [k0, l0]: all factors of a pass are computed from the same matrix (Jacobi form of the
+        // Parlett-Reinsch iteration; powers of two, so the similarity is exact in floating point)
+        for (int pass = 0; pass < 16; ++pass) {
+            double f = 1.0;
+            if (lane >= k0 && lane <= l0) {
+                double c = 0.0, r = 0.0;
+                for (int j = k0; j <= l0; ++j) {
+                    if (j != lane) {
+                        c += fabs(s[j * kHessLd + lane]);
+                        r += fabs(s[lane * kHessLd + j]);
+                    }
+                }
+                if (c != 0.0 && r != 0.0 && c < 1e300 && r < 1e300) {
+                    const double s0 = c + r;
+                    double g = r * 0.5;
+                    while (c < g) {
+                        f *= 2.0;
+                        c *= 4.0;
+                    }
+                    g = r * 2.0;
+                    while (c >= g) {
+                        f *= 0.5;
+                        c *= 0.25;
+                    }
+                    if ((c + r) / f >= 0.95 * s0) f = 1.0;
+                }
+            }
+            if (__ballot(f != 1.0) == 0ULL) break;
+            // A(r, c) <- A(r, c) * f_c / f_r   (lane = column c; f_r broadcast from lane r)
+            for (int r = 0; r < n; ++r) {
+                const double fr = bcast_lane(f, r);
+                if (inr) s[r * kHessLd + lane] = s[r * kHessLd + lane] * f / fr;
+            }
+            wave_lds_sync();
+        }
     }
 
     for (int k = 0; k < n - 2; ++k) {
@@ -641,8 +737,11 @@ int hess_real_launch(const double* a, int64_t nmat, int n, int lda, int64_t stri
     if (st) return st;
     const size_t hess_lds = (size_t)kHessWaves * kHessStride * sizeof(double);
     const unsigned gh = (unsigned)((nmat + kHessWaves - 1) / kHessWaves);
+    // balancing (xGEBAL) belongs to the eigenvalue driver: the stand-alone Hessenberg entry point (scale_exp == null)
+    // returns a matrix orthogonally similar to its input, without it
+    const int balance = (scale_exp != nullptr && !getenv("EGS_NO_BALANCE")) ? 1 : 0;
     hipLaunchKernelGGL(hess_real_kernel, dim3(gh), dim3(kHessWaves * kWave), hess_lds, stream, a, nmat, n, lda, stride,
-                       h, scale_exp);
+                       h, scale_exp, balance);
     EGS_LAUNCH_CHECK();
     return 0;
 }

@@ -450,3 +450,154 @@ def test_norm_attention_fast_path_vs_oracle(gpu_ops, d, h, fn, use_off):
     want = O.eta_norm(x, w, b, off, fn, d_qk, h, d)[..., 0]
     assert got.shape == want.shape == (bsz, seqlen - 1, h)
     np.testing.assert_allclose(got, want, rtol=3e-5)
+
+
+# ---- rare data-dependent branches (exceptional shifts, sweeps started below a small subdiagonal) -------------------
+def _cyclic(n):
+    p = np.zeros((n, n))
+    p[np.arange(1, n), np.arange(n - 1)] = 1.0
+    p[0, n - 1] = 1.0
+    return p
+
+
+@pytest.mark.parametrize("n", [3, 4, 8, 16, 33, 64])
+def test_eig_real_cyclic_permutation_needs_exceptional_shifts(gpu_ops, n):
+    """The cyclic shift matrix is an orthogonal Hessenberg matrix on which the standard double shift is stationary
+    (trailing 2x2 block [[0,0],[1,0]] gives zero shifts forever): convergence relies on the exceptional shifts taken
+    every 10 stalled iterations.  Its spectrum is known in closed form (the n-th roots of unity)."""
+    mats = np.stack([_cyclic(n), 2.5 * _cyclic(n), -_cyclic(n).T])
+    w, info = gpu_ops.eig_general_batched(dev(mats))
+    assert int(info.abs().sum()) == 0
+    roots = np.exp(2j * np.pi * np.arange(n) / n)
+    w = w.cpu().numpy()
+    assert O.max_abs_dlambda(w[0], roots) < 1e-10
+    assert O.max_abs_dlambda(w[1], 2.5 * roots) < 1e-10
+    assert O.max_abs_dlambda(w[2], -roots) < 1e-10
+
+
+@pytest.mark.parametrize("n", [4, 16, 64, 100])
+def test_eig_complex_cyclic_permutation(gpu_ops, n):
+    phase = np.exp(0.3j)
+    mats = np.stack([_cyclic(n).astype(complex) * phase, (1 + 2j) * _cyclic(n).T])
+    w, info = gpu_ops.eig_general_batched(dev(mats))
+    assert int(info.abs().sum()) == 0
+    roots = np.exp(2j * np.pi * np.arange(n) / n)
+    w = w.cpu().numpy()
+    assert O.max_abs_dlambda(w[0], phase * roots) < 1e-10
+    assert O.max_abs_dlambda(w[1], (1 + 2j) * roots) < 1e-10
+
+
+@pytest.mark.parametrize("n", [12, 40, 64])
+def test_eig_graded_matrices_small_subdiagonals(gpu_ops, n):
+    """Strongly graded Hessenberg-like matrices: many subdiagonal entries are tiny but not negligible, which exercises the
+    'two consecutive small subdiagonals' sweep start (m > l) and the conservative deflation criterion."""
+    rng = np.random.default_rng(n)
+    mats = []
+    for decay in (0.5, 0.2, 0.05):
+        g = decay ** np.arange(n)
+        a = rng.standard_normal((n, n)) * g[:, None] * 1.0            # rows scaled by a geometric grading
+        a += np.diag(np.linspace(1.0, 2.0, n))
+        mats.append(np.triu(a, -1))                                      # upper Hessenberg, graded subdiagonal
+    mats = np.stack(mats)
+    w, info = gpu_ops.eig_general_batched(dev(mats))
+    assert int(info.abs().sum()) == 0
+    ref = O.eigvals_dense(mats)
+    assert O.max_abs_dlambda(w.cpu().numpy(), ref) < 1e-8
+    wc, infoc = gpu_ops.eig_general_batched(dev(mats.astype(complex) * np.exp(0.7j)))
+    assert int(infoc.abs().sum()) == 0
+    assert O.max_abs_dlambda(wc.cpu().numpy(), ref * np.exp(0.7j)) < 1e-8
+
+
+def test_eig_randomised_differential(gpu_ops):
+    """Many small random cases of mixed structure against LAPACK (sizes 2..64, real and complex)."""
+    rng = np.random.default_rng(2026)
+    for n in (2, 3, 5, 7, 11, 17, 23, 32, 47, 64):
+        cases = []
+        for kind in range(6):
+            a = rng.standard_normal((n, n))
+            if kind == 1:
+                a = np.triu(a, -1)                                        # already Hessenberg
+            elif kind == 2:
+                a = a + a.T                                               # symmetric: real spectrum
+            elif kind == 3:
+                a = a - a.T                                               # skew: imaginary spectrum
+            elif kind == 4:
+                a[n // 2:, : n // 2] = 0.0                                # block triangular
+            elif kind == 5:
+                a = a * (rng.random((n, n)) < 0.3)                        # sparse
+            cases.append(a / max(1.0, np.sqrt(n)))
+        a = np.stack(cases)
+        w, info = gpu_ops.eig_general_batched(dev(a))
+        assert int(info.abs().sum()) == 0, n
+        err_scale = 1e-7 if n > 32 else 1e-9
+        assert O.max_abs_dlambda(w.cpu().numpy(), O.eigvals_dense(a)) < err_scale, n
+        ac = a + 1j * np.roll(a, 1, axis=0)
+        wc, infoc = gpu_ops.eig_general_batched(dev(ac))
+        assert int(infoc.abs().sum()) == 0, n
+        assert O.max_abs_dlambda(wc.cpu().numpy(), O.eigvals_dense(ac)) < err_scale, n
+
+
+@pytest.mark.parametrize("n", [6, 16, 40, 64])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_eig_balancing_badly_scaled(gpu_ops, n, cplx):
+    """A = D B D^-1 with D spanning 16 decades: without xGEBAL's diagonal scaling the small eigenvalues drown in the
+    rounding of the large entries; with it the spectrum of B comes back (numpy.linalg.eigvals balances too)."""
+    rng = np.random.default_rng(300 + n)
+    b = rng.standard_normal((4, n, n)) / np.sqrt(n)
+    if cplx:
+        b = b + 1j * rng.standard_normal((4, n, n)) / np.sqrt(n)
+    d = 2.0 ** rng.integers(-26, 27, size=(4, n)).astype(np.float64)       # exact similarity
+    a = d[:, :, None] * b / d[:, None, :]
+    ref = O.eigvals_dense(b)
+    w, info = gpu_ops.eig_general_batched(dev(a))
+    assert int(info.abs().sum()) == 0
+    err = O.max_abs_dlambda(w.cpu().numpy(), ref)
+    lap = O.max_abs_dlambda(O.eigvals_dense(a), ref)
+    assert err < max(1e-10, 50 * lap), (err, lap)
+
+
+@pytest.mark.parametrize("n", [5, 12, 33, 64])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_eig_balancing_isolates_eigenvalues(gpu_ops, n, cplx):
+    """Reducible matrices: P T P^T with T block upper triangular (triangular head and tail around a dense block).  The
+    permutation step of xGEBAL recovers the diagonal entries of the triangular parts EXACTLY, including defective
+    repeated ones that an unpermuted QR iteration can only resolve to eps^(1/k)."""
+    rng = np.random.default_rng(400 + n)
+    nb = 4
+    a = np.zeros((nb, n, n), dtype=np.complex128 if cplx else np.float64)
+    exact = []
+    for b in range(nb):
+        h, t = n // 3, n // 4
+        m = rng.standard_normal((n, n))
+        if cplx:
+            m = m + 1j * rng.standard_normal((n, n))
+        m[h:, :h] = 0.0
+        m[n - t:, : n - t] = 0.0
+        m[:h, :h] = np.triu(m[:h, :h])
+        m[n - t:, n - t:] = np.triu(m[n - t:, n - t:])
+        m[np.arange(h), np.arange(h)] = 0.5                                 # defective multiple eigenvalue
+        perm = rng.permutation(n)
+        a[b] = m[np.ix_(perm, perm)]
+        exact.append(np.concatenate([np.diag(m)[:h], np.diag(m)[n - t:]]))
+    w, info = gpu_ops.eig_general_batched(dev(a))
+    assert int(info.abs().sum()) == 0
+    w = w.cpu().numpy()
+    for b in range(nb):
+        for lam in exact[b]:
+            assert np.min(np.abs(w[b] - lam)) == 0.0, (b, lam)            # bit-exact isolated eigenvalues
+    assert O.max_abs_dlambda(w, O.eigvals_dense(a)) < 1e-9
+
+
+def test_eig_balancing_triangular_and_diagonal(gpu_ops):
+    """Fully reducible inputs (triangular, permuted triangular, diagonal) return the diagonal exactly."""
+    rng = np.random.default_rng(77)
+    for n in (1, 2, 7, 64):
+        t = np.triu(rng.standard_normal((n, n)))
+        perm = rng.permutation(n)
+        a = np.stack([t, t.T.copy(), t[np.ix_(perm, perm)], np.diag(np.diag(t))])
+        w, info = gpu_ops.eig_general_batched(dev(a))
+        assert int(info.abs().sum()) == 0
+        w = w.cpu().numpy()
+        for b in range(4):
+            assert np.array_equal(np.sort(w[b].real), np.sort(np.diag(t))), (n, b)
+            assert np.all(w[b].imag == 0.0)
