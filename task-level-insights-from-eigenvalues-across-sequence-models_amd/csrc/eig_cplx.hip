@@ -12,6 +12,8 @@
 // The working copy of the matrix lives in LDS when it fits (n <= 96), otherwise in the caller's workspace
 // (L2 / Infinity-Cache resident: 1 MB per 256 x 256 matrix).  Subdiagonals are NOT kept real (LAPACK rescales
 // to keep them real; the general-complex reflector formulas below do not need that).
+#include <stdlib.h>
+
 #include "egs_common.h"
 
 namespace egs {
@@ -80,7 +82,7 @@ template <bool INREAL, bool LDS>
 __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __restrict__ a, int n, int lda,
                                                              int64_t stride, double* __restrict__ w,
                                                              int32_t* __restrict__ info_out,
-                                                             double* __restrict__ work) {
+                                                             double* __restrict__ work, int balance) {
     extern __shared__ double dyn[];
     __shared__ double red[kCThreads / 64];
     __shared__ int s_idx;
@@ -112,6 +114,143 @@ __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __res
         for (int j = tid; j < 2 * n; j += kCThreads) wbad[j] = qnan;
         if (tid == 0) info_out[mat] = n;
         return;
+    }
+
+    // ---- phase 0: xGEBAL (what xGEEV does before the reduction) ----
+    // Permutation: rows / columns whose off-diagonal part inside the active window is zero isolate an eigenvalue and
+    // are swapped to the ends (their exact zeros survive the reflectors below, so the QR phase deflates them at once,
+    // bit-exactly).  Candidate search keeps per-row / per-column nonzero counts up to date, O(n) per isolated
+    // eigenvalue.  Scaling: Jacobi-form Parlett-Reinsch passes with power-of-two factors on the window [k0, l0].
+    if (balance) {
+        double* cn = reinterpret_cast<double*>(vsh + n);
+        double* rn = cn + n;
+        double* fs = rn + n;
+        int* cnt = reinterpret_cast<int*>(fs + n);
+        const int lane = tid & 63, wv = tid >> 6;
+#define ZNZ(i, j) (HM(i, j).re != 0.0 || HM(i, j).im != 0.0)
+#define ZSWAP(x, y)        \
+    {                      \
+        const zc t_ = (x); \
+        (x) = (y);         \
+        (y) = t_;          \
+    }
+        int k0 = 0, l0 = n - 1;
+        for (int i = wv; i < n; i += kCThreads / 64) {              // wave per row, lanes over columns
+            double c = 0.0;
+            for (int j = lane; j < n; j += 64) c += (j != i && ZNZ(i, j)) ? 1.0 : 0.0;
+            c = wave_sum(c);
+            if (lane == 0) cnt[i] = (int)c;
+        }
+        __syncthreads();
+        while (l0 > 0) {
+            if (tid == 0) s_idx = -1;
+            __syncthreads();
+            for (int i = tid; i <= l0; i += kCThreads)
+                if (cnt[i] == 0) atomicMax(&s_idx, i);
+            __syncthreads();
+            const int r = s_idx;
+            __syncthreads();
+            if (r < 0) break;
+            if (r != l0) {
+                for (int t = tid; t <= l0; t += kCThreads) ZSWAP(HM(t, r), HM(t, l0));
+                __syncthreads();
+                for (int t = tid; t < n; t += kCThreads) ZSWAP(HM(r, t), HM(l0, t));
+                if (tid == 0) {
+                    const int c = cnt[r];
+                    cnt[r] = cnt[l0];
+                    cnt[l0] = c;
+                }
+                __syncthreads();
+            }
+            for (int t = tid; t < l0; t += kCThreads)                // column l0 leaves the window
+                if (ZNZ(t, l0)) cnt[t] -= 1;
+            --l0;
+            __syncthreads();
+        }
+        for (int j = tid; j <= l0; j += kCThreads) {                // thread per column
+            int c = 0;
+            for (int i = 0; i <= l0; ++i) c += (i != j && ZNZ(i, j)) ? 1 : 0;
+            cnt[j] = c;
+        }
+        __syncthreads();
+        while (k0 < l0) {
+            if (tid == 0) s_idx = n;
+            __syncthreads();
+            for (int j = k0 + tid; j <= l0; j += kCThreads)
+                if (cnt[j] == 0) atomicMin(&s_idx, j);
+            __syncthreads();
+            const int c = s_idx;
+            __syncthreads();
+            if (c >= n) break;
+            if (c != k0) {
+                for (int t = tid; t <= l0; t += kCThreads) ZSWAP(HM(t, c), HM(t, k0));
+                __syncthreads();
+                for (int t = k0 + tid; t < n; t += kCThreads) ZSWAP(HM(c, t), HM(k0, t));
+                if (tid == 0) {
+                    const int q = cnt[c];
+                    cnt[c] = cnt[k0];
+                    cnt[k0] = q;
+                }
+                __syncthreads();
+            }
+            for (int t = k0 + 1 + tid; t <= l0; t += kCThreads)     // row k0 leaves the window
+                if (ZNZ(k0, t)) cnt[t] -= 1;
+            ++k0;
+            __syncthreads();
+        }
+        for (int pass = 0; pass < 16; ++pass) {
+            for (int j = k0 + tid; j <= l0; j += kCThreads) {
+                double c = 0.0;
+                for (int i = k0; i <= l0; ++i)
+                    if (i != j) c += zabs1(HM(i, j));
+                cn[j] = c;
+            }
+            for (int i = k0 + wv; i <= l0; i += kCThreads / 64) {
+                double r = 0.0;
+                for (int j = k0 + lane; j <= l0; j += 64)
+                    if (j != i) r += zabs1(HM(i, j));
+                r = wave_sum(r);
+                if (lane == 0) rn[i] = r;
+            }
+            if (tid == 0) s_idx = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += kCThreads) {
+                double f = 1.0;
+                if (i >= k0 && i <= l0) {
+                    double c = cn[i];
+                    const double r = rn[i];
+                    if (c != 0.0 && r != 0.0 && c < 1e300 && r < 1e300) {
+                        const double s0 = c + r;
+                        double g = r * 0.5;
+                        while (c < g) {
+                            f *= 2.0;
+                            c *= 4.0;
+                        }
+                        g = r * 2.0;
+                        while (c >= g) {
+                            f *= 0.5;
+                            c *= 0.25;
+                        }
+                        if ((c + r) / f >= 0.95 * s0) f = 1.0;
+                    }
+                }
+                fs[i] = f;
+                if (f != 1.0) s_idx = 1;
+            }
+            __syncthreads();
+            const bool any = s_idx != 0;
+            __syncthreads();
+            if (!any) break;
+            for (int idx = tid; idx < n * n; idx += kCThreads) {
+                const int i = idx / n, j = idx - i * n;
+                HM(i, j) = zscale(HM(i, j), fs[j] / fs[i]);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_idx = 0;
+        __syncthreads();
+#undef ZNZ
+#undef ZSWAP
     }
 
     // ---- phase 1: Hessenberg reduction ----
@@ -355,13 +494,16 @@ int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, i
         if (st) return st;
         return zhqr_wave_launch(wk, nmat, n, w, info, stream);
     }
-    const size_t dyn = lds ? ((size_t)n * (n + 1) + n) * 2 * sizeof(double) : (size_t)n * 2 * sizeof(double);
+    // working copy (LDS path) + Householder vector (n complex) + balancing scratch (4 n doubles)
+    const size_t dyn = (lds ? ((size_t)n * (n + 1) + n) * 2 : (size_t)n * 2) * sizeof(double) + (size_t)n * 4 * sizeof(double);
+    const int balance = getenv("EGS_NO_BALANCE") ? 0 : 1;
     const double* ap = static_cast<const double*>(a);
     auto launch = [&](auto kern) -> int {
         if (dyn > 48 * 1024)
             EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nmat), dim3(kCThreads), dyn, stream, ap, n, lda, stride, w, info, wk);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nmat), dim3(kCThreads), dyn, stream, ap, n, lda, stride, w, info, wk,
+                           balance);
         EGS_LAUNCH_CHECK();
         return 0;
     };

@@ -537,7 +537,7 @@ def test_eig_randomised_differential(gpu_ops):
         assert O.max_abs_dlambda(wc.cpu().numpy(), O.eigvals_dense(ac)) < err_scale, n
 
 
-@pytest.mark.parametrize("n", [6, 16, 40, 64])
+@pytest.mark.parametrize("n", [6, 16, 40, 64, 80, 130])
 @pytest.mark.parametrize("cplx", [False, True])
 def test_eig_balancing_badly_scaled(gpu_ops, n, cplx):
     """A = D B D^-1 with D spanning 16 decades: without xGEBAL's diagonal scaling the small eigenvalues drown in the
@@ -556,7 +556,7 @@ def test_eig_balancing_badly_scaled(gpu_ops, n, cplx):
     assert err < max(1e-10, 50 * lap), (err, lap)
 
 
-@pytest.mark.parametrize("n", [5, 12, 33, 64])
+@pytest.mark.parametrize("n", [5, 12, 33, 64, 96, 150])
 @pytest.mark.parametrize("cplx", [False, True])
 def test_eig_balancing_isolates_eigenvalues(gpu_ops, n, cplx):
     """Reducible matrices: P T P^T with T block upper triangular (triangular head and tail around a dense block).  The
@@ -591,7 +591,7 @@ def test_eig_balancing_isolates_eigenvalues(gpu_ops, n, cplx):
 def test_eig_balancing_triangular_and_diagonal(gpu_ops):
     """Fully reducible inputs (triangular, permuted triangular, diagonal) return the diagonal exactly."""
     rng = np.random.default_rng(77)
-    for n in (1, 2, 7, 64):
+    for n in (1, 2, 7, 64, 90, 200):
         t = np.triu(rng.standard_normal((n, n)))
         perm = rng.permutation(n)
         a = np.stack([t, t.T.copy(), t[np.ix_(perm, perm)], np.diag(np.diag(t))])
