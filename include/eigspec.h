@@ -162,6 +162,32 @@ int egs_threshold_hist(const void* vals, int dtype, int transform, int64_t outer
                        int64_t inner, const double* edges_host, int nedges, double* pct,
                        egs_stream_t stream);
 
+/* ---- 8(f) rank 2: block forward (token mixers that produce the next layer's input, quirk Q1) ----------
+ * One fp32 recurrence, evaluated token by token per batch row:
+ *     S_t = a_t S_{t-1} + k_t (s_t v_t)^T,      y_t = w_t (q_t^T S_t) + skip * v_t
+ * Replaces
+ *   SelfLinAttention.forward   (models/attention.py:58-83)      phi = 1, normalise = 1 (w_t = 1 / q_t.sum_{s<=t} k_s)
+ *   SelfNormAttention.forward / FlashNormAttention.forward (models/norm_attention.py:61-89, :129-156; the fla
+ *       chunk_simple_gla(q, k, v, None, scale) call)            phi = approx_fn == "elu", k_scale = scale, w = n
+ *   mamba_chunk_scan_combined(x, dt, A, B, C, D=D, z=None) as called by SSD / SSD_LTI.forward
+ *       (models/mamba.py:138-150, :276-288; mamba_ssm 2.x)      q = C, k = B, v = x, decay = exp(dt A), vscale = dt, skip = D
+ * Layout (all float32; strides in elements):
+ *   q, k   : [B, L, G, d_state] through (qk_batch_stride, qk_token_stride, qk_group_stride), d_state contiguous;
+ *            G = channels / cols_per_group (attention: heads; SSD: B/C groups)
+ *   v      : [B, L, channels] through (v_batch_stride, v_token_stride), channels contiguous
+ *   decay, vscale : [B, L, channels / cols_per_decay] contiguous, or NULL (= 1)
+ *   w      : [B, L, G] contiguous or NULL (= 1); ignored when normalise != 0
+ *   skip   : [channels] or NULL (= 0)
+ *   y      : [B, L, channels] contiguous
+ * d_state <= 512.  Workspace: egs_linrec_workspace_bytes (compact transformed q, k and the normaliser). */
+size_t egs_linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int d_state);
+int egs_linear_recurrence_fwd(const float* q, const float* k, int64_t qk_batch_stride, int64_t qk_token_stride,
+                              int64_t qk_group_stride, const float* v, int64_t v_batch_stride,
+                              int64_t v_token_stride, const float* decay, const float* vscale, const float* w,
+                              const float* skip, float* y, int64_t batch, int64_t seqlen, int channels,
+                              int d_state, int cols_per_group, int cols_per_decay, int phi, float k_scale,
+                              int normalise, void* workspace, size_t workspace_bytes, egs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,489 @@
+// Block forward: the token mixers whose OUTPUT feeds the next layer's eigenvalue analysis
+// (quirk Q1: eval_eig.py:513-517 computes layer i's spectrum from block i's output).
+//
+// One recurrence covers every linear-time mixer of the reference:
+//
+//     S_t = a_t * S_{t-1} + k_t (s_t v_t)^T          S: [d_state x channels], per batch row
+//     y_t = w_t * (q_t^T S_t) + skip * v_t
+//
+//   * causal linear attention        models/attention.py:58-83      a = 1, q,k = elu+1, w_t = 1 / (q_t . sum_{s<=t} k_s)
+//   * normalised linear attention    models/norm_attention.py:61-89 (and the fla chunk_simple_gla call :139-142 with
+//                                    g = None)                      a = 1, k scaled, w_t = exp(-norm_fn(n_t + offset))
+//   * Mamba-2 SSD                    models/mamba.py:138-150 (mamba_ssm 2.x mamba_chunk_scan_combined, z = None)
+//                                                                   a = exp(dt A) (= the eigenvalue lambda_t), s = dt,
+//                                                                   q = C, k = B, v = x, skip = D
+//   * pseudo-LTI SSD                 models/mamba.py:276-288        a = exp(beta A), s = beta, k = dt * B
+//
+// The recurrence is evaluated token by token in fp32, in the order of the reference's torch.cumsum: lane = channel, a
+// wave keeps DR state rows of 64 or 128 channels in VGPRs and applies 2 (3 with decay) packed FMAs per state-row pair
+// per token -- the algorithmic minimum of this form (fp32 MFMA has the same peak as packed fp32 VALU on gfx950, and a
+// chunked MFMA formulation needs 1.4-1.7x the flops).  q_t / k_t are wave-uniform operands; how they reach the FMAs is
+// what bounds the kernel (see linrec_kernel).  d_state is split over the RS waves of a workgroup (16 rows each) whose
+// partial y meet in LDS once per 4 tokens.
+// The elementwise q/k preparation (elu+1, scale, zero padding to the register tile) is a separate streaming pass into a
+// compact record stream [B][G][RS][L][q | k][DR] -- one contiguous record per (wave, token); w_t of linear attention
+// comes from a lane-per-token prefix pass over that stream.
+#include <stdlib.h>
+
+#include "egs_common.h"
+
+namespace egs {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kRecT = 4;          // tokens per block (prefetch / LDS exchange granularity)
+constexpr int kRecPad = 8;        // record streams are zero-padded to a multiple of this many tokens
+
+__device__ __forceinline__ float phi_elu1(float x) { return x > 0.0f ? x + 1.0f : __expf(x); }
+
+// raw strided q, k  ->  compact, transformed, zero-padded stream  [B][G][RS][L][2 (q, k)][DR]:
+// the wave that owns state rows [r DR, (r+1) DR) reads one contiguous 2 DR-float record per token.
+// grid = (blocks over a slab, G * RS, B); 4 consecutive record floats per thread (DR is a power of two >= 16).
+__global__ __launch_bounds__(256) void qk_transform_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           int64_t bs, int64_t ts, int64_t gs, float* __restrict__ qk,
+                                                           int64_t seqlen, int64_t seqpad, int groups, int d,
+                                                           int dr_log2, int rs, int phi, float kscale, int vec4) {
+    const int dr = 1 << dr_log2;
+    const int r = blockIdx.y % rs;
+    const int g = blockIdx.y / rs;
+    const int64_t b = blockIdx.z;
+    const int64_t slab = seqpad * 2 * dr;                             // floats per (b, g, r); tokens >= seqlen are zero
+    float* dst = qk + ((b * groups + g) * rs + r) * slab;
+    for (int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i4 < slab;
+         i4 += (int64_t)gridDim.x * blockDim.x * 4) {
+        const int dd = (int)(i4 & (dr - 1));
+        const int which = (int)(i4 >> dr_log2) & 1;
+        const int64_t t = i4 >> (dr_log2 + 1);
+        const bool pad = t >= seqlen;
+        const float* src = (which ? k : q) + b * bs + (pad ? seqlen - 1 : t) * ts + (int64_t)g * gs;
+        float out[4];
+        float in[4];
+        const int row0 = r * dr + dd;
+        if (vec4) {                                                   // d % 4 == 0, 16-byte aligned rows: one load
+            const float4 x = *reinterpret_cast<const float4*>(src + (row0 < d ? row0 : d - 4));
+            in[0] = x.x, in[1] = x.y, in[2] = x.z, in[3] = x.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) in[e] = src[row0 + e < d ? row0 + e : d - 1];   // clamped, unconditional
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = row0 + e;
+            float val = in[e];
+            if (phi) val = val > 0.0f ? val + 1.0f : expm1f(val) + 1.0f;   // F.elu(x) + 1
+            if (which) val *= kscale;
+            out[e] = (row < d && !pad) ? val : 0.0f;
+        }
+        *reinterpret_cast<float4*>(dst + i4) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (row_shr 1/2/4/8, then row_bcast15 / row_bcast31)
+__device__ __forceinline__ float wave_inclusive_scan(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, false));
+    return x;
+}
+
+// nu_r[b, g, r, t] = sum_{d in slice r} q_t[d] * sum_{s<=t} k_s[d]   (models/attention.py:74-75, one slice of d).
+// One wave per (b, g, r); lane = token of a 64-token chunk: the chunk's k values of every state row are prefix-summed
+// across the lanes (6 DPP adds), the running totals of earlier chunks are wave-uniform registers.  The records of the
+// next chunk are loaded while the current one is scanned.
+template <int DR>
+__global__ __launch_bounds__(64) void linattn_nu_kernel(const float* __restrict__ qk, float* __restrict__ nu_part,
+                                                        int64_t seqlen, int64_t seqpad) {
+    const int lane = threadIdx.x;
+    const int64_t slab = blockIdx.x;                                  // (b * G + g) * RS + r
+    const float* base = qk + slab * seqpad * (2 * DR);
+    float carry[DR];
+#pragma unroll
+    for (int i = 0; i < DR; ++i) carry[i] = 0.0f;
+    float4 nq[DR / 4], nk[DR / 4];
+    {
+        const int64_t tc = lane < seqlen ? lane : seqlen - 1;
+#pragma unroll
+        for (int i = 0; i < DR / 4; ++i) {
+            nq[i] = *reinterpret_cast<const float4*>(base + tc * (2 * DR) + 4 * i);
+            nk[i] = *reinterpret_cast<const float4*>(base + tc * (2 * DR) + DR + 4 * i);
+        }
+    }
+    for (int64_t t0 = 0; t0 < seqlen; t0 += 64) {
+        const int64_t t = t0 + lane;
+        const bool live = t < seqlen;
+        float4 cq[DR / 4], ck[DR / 4];
+#pragma unroll
+        for (int i = 0; i < DR / 4; ++i) {
+            cq[i] = nq[i];
+            ck[i] = nk[i];
+        }
+        {
+            const int64_t tn = (t + 64 < seqlen) ? t + 64 : seqlen - 1;
+#pragma unroll
+            for (int i = 0; i < DR / 4; ++i) {
+                nq[i] = *reinterpret_cast<const float4*>(base + tn * (2 * DR) + 4 * i);
+                nk[i] = *reinterpret_cast<const float4*>(base + tn * (2 * DR) + DR + 4 * i);
+            }
+        }
+        float p = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DR / 4; ++i) {
+            const float qs[4] = {cq[i].x, cq[i].y, cq[i].z, cq[i].w};
+            const float kk[4] = {ck[i].x, ck[i].y, ck[i].z, ck[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sc = wave_inclusive_scan(live ? kk[e] : 0.0f);
+                p = fmaf(qs[e], carry[4 * i + e] + sc, p);
+                carry[4 * i + e] += bcast_lane(sc, 63);
+            }
+        }
+        if (live) nu_part[slab * seqlen + t] = p;
+    }
+}
+
+// w[b, t, g] = 1 / sum_r nu_r   (models/attention.py:76: n.pow(-1))
+__global__ __launch_bounds__(256) void linattn_w_finish_kernel(const float* __restrict__ nu_part, float* __restrict__ w,
+                                                               int64_t batch, int64_t seqlen, int groups, int rs) {
+    const int64_t total = batch * seqlen * groups;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % groups);
+        const int64_t bt = idx / groups;
+        const int64_t t = bt % seqlen;
+        const int64_t b = bt / seqlen;
+        float nu = 0.0f;
+        for (int r = 0; r < rs; ++r) nu += nu_part[(((b * groups + g) * rs + r) * seqlen) + t];
+        w[idx] = 1.0f / nu;
+    }
+}
+
+struct RecArgs {
+    const float* v;         // [B][L][C] with strides
+    int64_t v_bs, v_ts;
+    const float* decay;     // [B][L][C / cpd] or null
+    const float* vscale;    // [B][L][C / cpd] or null
+    const float* w;         // [B][L][G] or null
+    const float* skip;      // [C] or null
+    float* y;               // [B][L][C]
+    int64_t seqlen;
+    int channels, groups, cpg, cpd, tiles_per_group;
+};
+
+// One workgroup = RS waves = one (batch row, CT x 64 channels of one q/k group); wave r owns state rows
+// [r DR, (r+1) DR) of those channels in CT * DR VGPRs.
+// Operand delivery: q_t / k_t are wave-uniform.  Three routes were measured on the C4/8 shard (profiles/r01_blocks.json):
+// scalar loads (every 64-byte line is used once and the scalar cache's miss path cannot stream: halving the scalar
+// traffic per FMA halved the run time), one v_readlane_b32 per element (doubles the VALU instruction count, and the
+// kernel is instruction-issue bound), and -- what is used -- staging each wave's records of a 4-token block in LDS
+// (one coalesced 8-byte load per lane, fetched a block ahead) and reading them back with uniform-address
+// ds_read_b128: 4 operands per LDS instruction, delivered as VGPR pairs to v_pk_fma_f32.
+// Per-lane operands (v, decay, dt) of block n+1 are loaded while block n computes; the partial y of the RS waves meet
+// in a double-buffered LDS array (one barrier per block).  Records are zero-padded to a multiple of kRecPad tokens.
+template <int DR, int CT, int RS, bool DECAY>
+__global__ __launch_bounds__(RS * 64) void linrec_kernel(const float* __restrict__ qk, RecArgs a) {
+    __shared__ float part[RS > 1 ? 2 * RS * kRecT * CT * 64 : 1];
+    constexpr int kBlk = kRecT * 2 * DR;                              // floats of one wave's records per block
+    constexpr int NV = (kBlk + 63) / 64;                              // staged floats per lane (DR = 16: 2)
+    __shared__ __attribute__((aligned(16))) float stage[RS * kBlk];
+    const int lane = threadIdx.x & 63;
+    const int r = uniform(threadIdx.x >> 6);
+    const int tile = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    const int g = tile / a.tiles_per_group;
+    const int ct0 = (tile - g * a.tiles_per_group) * CT;
+    const unsigned nh = (unsigned)(a.channels / a.cpd);
+    const int64_t L = a.seqlen;
+    const int64_t Lp = (L + kRecPad - 1) / kRecPad * kRecPad;
+    const float* rec = qk + (((b * a.groups + g) * RS + r) * Lp) * (2 * DR);
+    const bool has_w = a.w != nullptr;
+
+    // per-row uniform bases (SGPR) + 32-bit lane offsets
+    const float* vrow = a.v + b * a.v_bs;
+    const float* drow = DECAY ? a.decay + b * L * nh : vrow;
+    const float* srow = DECAY ? a.vscale + b * L * nh : vrow;
+    const float* wrow = has_w ? a.w + b * L * a.groups + g : vrow;   // always-valid address, selected by value
+    float* yrow = a.y + b * L * a.channels;
+    const unsigned vts = (unsigned)a.v_ts, wstride = has_w ? (unsigned)a.groups : 0u;
+    const unsigned lastt = (unsigned)(L - 1);
+    bool active[CT];
+    unsigned ch[CT], head[CT];
+    float skipc[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+        const int col = (ct0 + j) * 64 + lane;                        // column inside the group
+        active[j] = col < a.cpg;
+        ch[j] = (unsigned)(g * a.cpg + (active[j] ? col : 0));        // clamped channel
+        head[j] = ch[j] / (unsigned)a.cpd;
+        skipc[j] = a.skip ? a.skip[ch[j]] : 0.0f;
+    }
+    float* mystage = stage + r * kBlk;
+    const float* recl = rec + lane * NV;                              // this lane's NV consecutive floats of a block
+
+    f32x2 st[CT][DR / 2];
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int i = 0; i < DR / 2; ++i) st[j][i] = {0.0f, 0.0f};
+
+    // operands of the NEXT block: nothing a block loads is consumed inside that block (vmcnt retires in order, so one
+    // early use would drain the whole prefetch)
+    float vn[CT][kRecT], an[CT][kRecT], sn[CT][kRecT], rn[NV], wn[kRecT];
+#pragma unroll
+    for (int x = 0; x < NV; ++x) rn[x] = recl[x];
+#pragma unroll
+    for (int u = 0; u < kRecT; ++u) {
+        const unsigned t = min((unsigned)u, lastt);
+        wn[u] = wrow[t * wstride];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            vn[j][u] = vrow[t * vts + ch[j]];
+            an[j][u] = DECAY ? drow[t * nh + head[j]] : 1.0f;
+            sn[j][u] = DECAY ? srow[t * nh + head[j]] : 1.0f;
+        }
+    }
+    int buf = 0;
+    for (int64_t t0 = 0; t0 < L; t0 += kRecT) {
+        float vv[CT][kRecT], aa[CT][kRecT], ss[CT][kRecT], ww[kRecT];
+        // this wave's records of the block: registers -> LDS (wave-private region, no workgroup barrier needed)
+#pragma unroll
+        for (int x = 0; x < NV; ++x) mystage[lane * NV + x] = rn[x];
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < kRecT; ++u) {
+            ww[u] = has_w ? wn[u] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                vv[j][u] = vn[j][u];
+                aa[j][u] = an[j][u];
+                ss[j][u] = sn[j][u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kRecT; ++u) {                            // issued now, consumed one block later
+            const unsigned t = min((unsigned)(t0 + kRecT + u), lastt);
+            wn[u] = wrow[t * wstride];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                vn[j][u] = vrow[t * vts + ch[j]];
+                an[j][u] = DECAY ? drow[t * nh + head[j]] : 1.0f;
+                sn[j][u] = DECAY ? srow[t * nh + head[j]] : 1.0f;
+            }
+        }
+        {
+            const int64_t nb = (t0 + kRecT < Lp) ? t0 + kRecT : t0;   // next block of records (the stream is padded)
+#pragma unroll
+            for (int x = 0; x < NV; ++x) rn[x] = recl[nb * (2 * DR) + x];
+        }
+#pragma unroll
+        for (int u = 0; u < kRecT; ++u) {
+            f32x2 acc[CT];
+            f32x2 vs2[CT], a2[CT];
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                acc[j] = {0.0f, 0.0f};
+                const float vs = vv[j][u] * ss[j][u];
+                vs2[j] = {vs, vs};
+                a2[j] = {aa[j][u], aa[j][u]};
+            }
+#pragma unroll
+            for (int i = 0; i < DR / 2; i += 2) {
+                // record = [q_0 .. q_{DR-1} | k_0 .. k_{DR-1}]; uniform-address 16-byte LDS reads
+                const float4 q4 = *reinterpret_cast<const float4*>(mystage + u * (2 * DR) + 2 * i);
+                const float4 k4 = *reinterpret_cast<const float4*>(mystage + u * (2 * DR) + DR + 2 * i);
+                const f32x2 qa = {q4.x, q4.y}, qb = {q4.z, q4.w}, ka = {k4.x, k4.y}, kb = {k4.z, k4.w};
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    if (DECAY) {
+                        st[j][i] = st[j][i] * a2[j] + ka * vs2[j];
+                        st[j][i + 1] = st[j][i + 1] * a2[j] + kb * vs2[j];
+                    } else {
+                        st[j][i] = ka * vs2[j] + st[j][i];
+                        st[j][i + 1] = kb * vs2[j] + st[j][i + 1];
+                    }
+                    acc[j] = qa * st[j][i] + acc[j];
+                    acc[j] = qb * st[j][i + 1] + acc[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                const float yp = acc[j].x + acc[j].y;
+                if (RS > 1) {
+                    part[(((buf * RS + r) * kRecT + u) * CT + j) * 64 + lane] = yp;
+                } else if (active[j] && t0 + u < L) {
+                    yrow[(unsigned)(t0 + u) * (unsigned)a.channels + ch[j]] = fmaf(ww[u], yp, skipc[j] * vv[j][u]);
+                }
+            }
+        }
+        if (RS > 1) {
+            __syncthreads();                                          // the other buffer is free again after this barrier
+#pragma unroll
+            for (int u = 0; u < kRecT; ++u) {
+                if ((u % RS) == r && t0 + u < L) {                    // wave-uniform: wave r finishes tokens u = r mod RS
+#pragma unroll
+                    for (int j = 0; j < CT; ++j) {
+                        float ysum = 0.0f;
+#pragma unroll
+                        for (int x = 0; x < RS; ++x) ysum += part[(((buf * RS + x) * kRecT + u) * CT + j) * 64 + lane];
+                        if (active[j])
+                            yrow[(unsigned)(t0 + u) * (unsigned)a.channels + ch[j]] =
+                                fmaf(ww[u], ysum, skipc[j] * vv[j][u]);
+                    }
+                }
+            }
+            buf ^= 1;
+        }
+    }
+}
+
+// Register tiling: CT column tiles per wave (2 when the group has an even number of 64-column tiles: every scalar
+// q/k operand then feeds two FMAs), RS waves per workgroup splitting d_state (DR = rows per wave in {16, 32, 64}).
+// RS grows until the launch has >= 4 waves per SIMD to hide the scalar-load latency, or DR reaches 16.
+struct RecTiling {
+    int dr, ct, rs, tpg;
+};
+static RecTiling linrec_tiling(int64_t batch, int channels, int cols_per_group, int d_state) {
+    RecTiling t;
+    const int groups = channels / cols_per_group;
+    const int tiles64 = (cols_per_group + 63) / 64;
+    t.ct = (tiles64 % 2 == 0) ? 2 : 1;
+    if (const char* e = getenv("EGS_REC_CT")) {                       // tuning knob (tools/bench_blocks.py)
+        if (atoi(e) == 1) t.ct = 1;
+    }
+    t.tpg = tiles64 / t.ct;
+    const int64_t wgs = batch * groups * t.tpg;
+    // measured (tools/bench_blocks.py, profiles/r01_blocks.json): the 16-row slice wins at every batch size -- the
+    // kernel is bound by scalar-load latency, which only more resident waves hide
+    (void)wgs;
+    int rs = 1;
+    while (rs < 8 && (d_state + rs - 1) / rs > 16) rs *= 2;
+    if (const char* e = getenv("EGS_REC_RS")) {                       // tuning knob (tools/bench_blocks.py)
+        const int v = atoi(e);
+        if ((v == 1 || v == 2 || v == 4 || v == 8) && (d_state + v - 1) / v <= 64) rs = v;
+    }
+    const int need = (d_state + rs - 1) / rs;
+    t.dr = need <= 16 ? 16 : need <= 32 ? 32 : 64;
+    t.rs = rs;
+    return t;
+}
+
+size_t linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int d_state) {
+    const RecTiling t = linrec_tiling(batch, channels, cols_per_group, d_state);
+    const int64_t groups = channels / cols_per_group;
+    // compact (q, k) records (zero-padded to a multiple of kRecPad tokens) + the normaliser w + its per-slice partials
+    const int64_t seqpad = (seqlen + kRecPad - 1) / kRecPad * kRecPad;
+    return (size_t)(2 * batch * groups * seqpad * t.dr * t.rs + batch * seqlen * groups * (1 + t.rs)) * sizeof(float) +
+           512;
+}
+
+template <int DR, int CT, int RS>
+static void linrec_dispatch(const float* qk, const RecArgs& a, int64_t batch, bool decay, hipStream_t stream) {
+    const dim3 grid((unsigned)(a.tiles_per_group * a.groups), (unsigned)batch);
+    if (decay) hipLaunchKernelGGL((linrec_kernel<DR, CT, RS, true>), grid, dim3(RS * 64), 0, stream, qk, a);
+    else hipLaunchKernelGGL((linrec_kernel<DR, CT, RS, false>), grid, dim3(RS * 64), 0, stream, qk, a);
+}
+
+int linrec_launch(const float* q, const float* k, int64_t qk_bs, int64_t qk_ts, int64_t qk_gs, const float* v,
+                  int64_t v_bs, int64_t v_ts, const float* decay, const float* vscale, const float* w,
+                  const float* skip, float* y, int64_t batch, int64_t seqlen, int channels, int d_state,
+                  int cols_per_group, int cols_per_decay, int phi, float k_scale, int normalise, void* workspace,
+                  size_t workspace_bytes, hipStream_t stream) {
+    if (batch == 0 || seqlen == 0) return 0;
+    if (d_state > 512) {
+        set_error("d_state = %d exceeds the supported maximum of 512", d_state);
+        return -17;
+    }
+    if (seqlen * (v_ts > channels ? v_ts : (int64_t)channels) >= (int64_t)1 << 31) {
+        set_error("seqlen * token stride = %lld exceeds the 32-bit per-row offsets of the kernel",
+                  (long long)(seqlen * (v_ts > channels ? v_ts : (int64_t)channels)));
+        return -15;
+    }
+    if ((decay == nullptr) != (vscale == nullptr)) {
+        set_error("decay and vscale must be given together (the gated form) or not at all");
+        return -10;
+    }
+    const int groups = channels / cols_per_group;
+    if (groups * 8 > 65535) {
+        set_error("too many q/k groups: %d", groups);
+        return -18;
+    }
+    const RecTiling tl = linrec_tiling(batch, channels, cols_per_group, d_state);
+    const size_t need_ws = linrec_workspace_bytes(batch, seqlen, channels, cols_per_group, d_state);
+    if (workspace_bytes < need_ws) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, need_ws);
+        return -24;
+    }
+    float* qk = static_cast<float*>(workspace);
+    const int64_t seqpad = (seqlen + kRecPad - 1) / kRecPad * kRecPad;
+    const int64_t total = 2 * batch * groups * seqpad * tl.dr * tl.rs;
+    {
+        const int dr_log2 = tl.dr == 16 ? 4 : tl.dr == 32 ? 5 : 6;
+        const int vec4 = (d_state % 4 == 0 && qk_bs % 4 == 0 && qk_ts % 4 == 0 && qk_gs % 4 == 0 &&
+                          reinterpret_cast<uintptr_t>(q) % 16 == 0 && reinterpret_cast<uintptr_t>(k) % 16 == 0)
+                             ? 1
+                             : 0;
+        const int64_t slab4 = seqpad * 2 * tl.dr / 4;
+        const int64_t blocks = (slab4 + 255) / 256;
+        const dim3 grid((unsigned)(blocks < 4096 ? blocks : 4096), (unsigned)(groups * tl.rs), (unsigned)batch);
+        hipLaunchKernelGGL(qk_transform_kernel, grid, dim3(256), 0, stream, q, k, qk_bs, qk_ts, qk_gs, qk, seqlen, seqpad,
+                           groups, d_state, dr_log2, tl.rs, phi, k_scale, vec4);
+        EGS_LAUNCH_CHECK();
+    }
+    float* wbuf = nullptr;
+    if (normalise) {
+        wbuf = qk + total;
+        float* nu_part = wbuf + batch * seqlen * groups;
+        const unsigned slabs = (unsigned)(batch * groups * tl.rs);
+        if (tl.dr == 16)
+            hipLaunchKernelGGL(linattn_nu_kernel<16>, dim3(slabs), dim3(64), 0, stream, qk, nu_part, seqlen, seqpad);
+        else if (tl.dr == 32)
+            hipLaunchKernelGGL(linattn_nu_kernel<32>, dim3(slabs), dim3(64), 0, stream, qk, nu_part, seqlen, seqpad);
+        else
+            hipLaunchKernelGGL(linattn_nu_kernel<64>, dim3(slabs), dim3(64), 0, stream, qk, nu_part, seqlen, seqpad);
+        EGS_LAUNCH_CHECK();
+        const int64_t tot = batch * seqlen * groups;
+        const int64_t blocks = (tot + 255) / 256;
+        hipLaunchKernelGGL(linattn_w_finish_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
+                           nu_part, wbuf, batch, seqlen, groups, tl.rs);
+        EGS_LAUNCH_CHECK();
+    }
+    RecArgs a;
+    a.v = v;
+    a.v_bs = v_bs;
+    a.v_ts = v_ts;
+    a.decay = decay;
+    a.vscale = vscale;
+    a.w = normalise ? wbuf : w;
+    a.skip = skip;
+    a.y = y;
+    a.seqlen = seqlen;
+    a.channels = channels;
+    a.groups = groups;
+    a.cpg = cols_per_group;
+    a.cpd = cols_per_decay;
+    a.tiles_per_group = tl.tpg;
+    const bool dec = decay != nullptr;
+#define EGS_REC_CASE(DRV, CTV, RSV)                                   \
+    if (tl.dr == DRV && tl.ct == CTV && tl.rs == RSV) {               \
+        linrec_dispatch<DRV, CTV, RSV>(qk, a, batch, dec, stream);    \
+        EGS_LAUNCH_CHECK();                                           \
+        return 0;                                                     \
+    }
+#define EGS_REC_CASES(CTV, RSV) EGS_REC_CASE(16, CTV, RSV) EGS_REC_CASE(32, CTV, RSV) EGS_REC_CASE(64, CTV, RSV)
+    EGS_REC_CASES(1, 1)
+    EGS_REC_CASES(1, 2)
+    EGS_REC_CASES(1, 4)
+    EGS_REC_CASES(1, 8)
+    EGS_REC_CASES(2, 1)
+    EGS_REC_CASES(2, 2)
+    EGS_REC_CASES(2, 4)
+    EGS_REC_CASES(2, 8)
+#undef EGS_REC_CASES
+#undef EGS_REC_CASE
+    set_error("internal: no register tiling for d_state = %d", d_state);
+    return -17;
+}
+
+}  // namespace egs

@@ -35,6 +35,10 @@ size_t attn_workspace_bytes(int64_t, int64_t, int, int);
 int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, const float*, int, int, double*, void*,
                     size_t, hipStream_t);
 int threshold_hist_launch(const void*, int, int, int64_t, int64_t, int64_t, const double*, int, double*, hipStream_t);
+size_t linrec_workspace_bytes(int64_t, int64_t, int, int, int);
+int linrec_launch(const float*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, const float*,
+                  const float*, const float*, const float*, float*, int64_t, int64_t, int, int, int, int, int, float, int,
+                  void*, size_t, hipStream_t);
 size_t eig_real_lds_workspace_bytes(int64_t, int);
 int eig_real_lds_launch(const double*, int64_t, int, int, int64_t, double*, int32_t*, void*, size_t, hipStream_t);
 int hess_real_launch(const double*, int64_t, int, int, int64_t, double*, int32_t*, hipStream_t);
@@ -233,6 +237,36 @@ int egs_threshold_hist(const void* vals, int dtype, int transform, int64_t outer
     EGS_ARG(pct != nullptr, 9);
     return threshold_hist_launch(vals, dtype, transform, outer, t_len, inner, edges_host, nedges, pct,
                                  as_stream(stream));
+}
+
+size_t egs_linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int d_state) {
+    if (batch <= 0 || seqlen <= 0 || channels <= 0 || cols_per_group <= 0 || d_state <= 0 ||
+        channels % cols_per_group != 0)
+        return 512;
+    return linrec_workspace_bytes(batch, seqlen, channels, cols_per_group, d_state);
+}
+
+int egs_linear_recurrence_fwd(const float* q, const float* k, int64_t qk_batch_stride, int64_t qk_token_stride,
+                              int64_t qk_group_stride, const float* v, int64_t v_batch_stride,
+                              int64_t v_token_stride, const float* decay, const float* vscale, const float* w,
+                              const float* skip, float* y, int64_t batch, int64_t seqlen, int channels,
+                              int d_state, int cols_per_group, int cols_per_decay, int phi, float k_scale,
+                              int normalise, void* workspace, size_t workspace_bytes, egs_stream_t stream) {
+    EGS_ARG(batch >= 0 && batch <= 65535, 14);
+    EGS_ARG(seqlen >= 0, 15);
+    EGS_ARG(channels > 0, 16);
+    EGS_ARG(d_state > 0 && d_state <= 512, 17);
+    EGS_ARG(cols_per_group > 0 && channels % cols_per_group == 0, 18);
+    EGS_ARG(cols_per_decay > 0 && channels % cols_per_decay == 0, 19);
+    if (batch == 0 || seqlen == 0) return 0;
+    EGS_ARG(q != nullptr, 1);
+    EGS_ARG(k != nullptr, 2);
+    EGS_ARG(v != nullptr, 6);
+    EGS_ARG(y != nullptr, 13);
+    EGS_ARG(workspace != nullptr, 23);
+    return linrec_launch(q, k, qk_batch_stride, qk_token_stride, qk_group_stride, v, v_batch_stride, v_token_stride,
+                         decay, vscale, w, skip, y, batch, seqlen, channels, d_state, cols_per_group, cols_per_decay,
+                         phi, k_scale, normalise, workspace, workspace_bytes, as_stream(stream));
 }
 
 }  // extern "C"

@@ -57,6 +57,10 @@ __device__ __forceinline__ double bcast_lane(double x, int src) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ float bcast_lane(float x, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), __builtin_amdgcn_readfirstlane(src)));
+}
+
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 __device__ __forceinline__ double wave_sum(double v) {

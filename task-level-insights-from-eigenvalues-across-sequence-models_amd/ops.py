@@ -240,3 +240,55 @@ def threshold_hist(vals, edges, transform="value"):
         check(lib().egs_threshold_hist(_ptr(vals), _DTYPES[vals.dtype], _TRANSFORMS[transform], outer, t_len, inner,
                                        c_edges, len(edges), _ptr(pct), _stream()), "egs_threshold_hist")
     return pct
+
+
+# ---- block forward ---------------------------------------------------------------
+def linear_recurrence_fwd(q, k, v, decay=None, vscale=None, w=None, skip=None, phi=False, k_scale=1.0,
+                          normalise=False, cols_per_decay=None):
+    """y_t = w_t (q_t^T S_t) + skip * v_t with S_t = decay_t S_{t-1} + k_t (vscale_t v_t)^T, fp32, per batch row.
+
+    q, k: [B, L, G, d] views with equal strides and contiguous last dim (slices of a projection output are fine);
+    v: [B, L, C] with contiguous channels, C = G * cols_per_group; decay / vscale: [B, L, C // cols_per_decay];
+    w: [B, L, G]; skip: [C].  ``normalise`` computes w_t = 1 / (q_t . sum_{s<=t} k_s) on the device instead.
+    Replaces the mixers of models/attention.py:58-83, models/norm_attention.py:61-89 and the
+    mamba_chunk_scan_combined calls of models/mamba.py:138-150, :276-288."""
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        _require_cuda(t, name)
+        if t.dtype != torch.float32:
+            raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if q.dim() != 4 or k.shape != q.shape or q.stride() != k.stride() or (q.shape[-1] > 1 and q.stride(-1) != 1):
+        raise ValueError("q and k must be [B, L, G, d] views with identical strides and a contiguous last dim")
+    batch, seqlen, groups, d_state = q.shape
+    if v.dim() != 3 or v.shape[:2] != q.shape[:2] or (v.shape[-1] > 1 and v.stride(-1) != 1):
+        raise ValueError("v must be [B, L, C] with contiguous channels")
+    channels = v.shape[-1]
+    if channels % groups != 0:
+        raise ValueError(f"channels ({channels}) must be a multiple of the q/k groups ({groups})")
+    cpg = channels // groups
+    cpd = cpg if cols_per_decay is None else int(cols_per_decay)
+    nh = channels // cpd
+
+    def _opt(t, shape, name):
+        if t is None:
+            return None
+        _require_cuda(t, name)
+        if tuple(t.shape) != shape:
+            raise ValueError(f"{name} must have shape {shape}, got {tuple(t.shape)}")
+        return t.to(torch.float32).contiguous()
+
+    decay = _opt(decay, (batch, seqlen, nh), "decay")
+    vscale = _opt(vscale, (batch, seqlen, nh), "vscale")
+    w = _opt(w, (batch, seqlen, groups), "w")
+    skip = _opt(skip, (channels,), "skip")
+    y = torch.empty((batch, seqlen, channels), dtype=torch.float32, device=v.device)
+    if batch == 0 or seqlen == 0:
+        return y
+    need = lib().egs_linrec_workspace_bytes(batch, seqlen, channels, cpg, d_state)
+    ws = _workspace(v.device, need)
+    with torch.cuda.device(v.device):
+        check(lib().egs_linear_recurrence_fwd(
+            _ptr(q), _ptr(k), q.stride(0), q.stride(1), q.stride(2), _ptr(v), v.stride(0), v.stride(1),
+            _ptr(decay), _ptr(vscale), _ptr(w), _ptr(skip), _ptr(y), batch, seqlen, channels, d_state, cpg, cpd,
+            1 if phi else 0, float(k_scale), 1 if normalise else 0, _ptr(ws), ws.numel() * ws.element_size(),
+            _stream()), "egs_linear_recurrence_fwd")
+    return y
