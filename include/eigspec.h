@@ -188,6 +188,16 @@ int egs_linear_recurrence_fwd(const float* q, const float* k, int64_t qk_batch_s
                               int d_state, int cols_per_group, int cols_per_decay, int phi, float k_scale,
                               int normalise, void* workspace, size_t workspace_bytes, egs_stream_t stream);
 
+/* Replaces SelfAttention.forward (models/attention.py:17-35) and, in fp32 instead of fp16, the flash_attn call of
+ * FlashAttention.forward (:46-55): y[b,t,h,:] = sum_{s<=t} softmax_s(scale * q_t.k_s) v_s, fp32.
+ *   q, k : [B, L, H, head_dim] through (qk_batch_stride, qk_token_stride, qk_head_stride), head_dim contiguous
+ *   v    : [B, L, H * v_dim]   through (v_batch_stride, v_token_stride), channels contiguous
+ *   y    : [B, L, H * v_dim]   contiguous */
+int egs_softmax_attention_fwd(const float* q, const float* k, int64_t qk_batch_stride, int64_t qk_token_stride,
+                              int64_t qk_head_stride, const float* v, int64_t v_batch_stride, int64_t v_token_stride,
+                              float* y, int64_t batch, int64_t seqlen, int num_heads, int head_dim, int v_dim,
+                              float scale, egs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -486,4 +486,181 @@ int linrec_launch(const float* q, const float* k, int64_t qk_bs, int64_t qk_ts, 
     return -17;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Causal softmax attention forward (SelfAttention.forward, models/attention.py:17-35; the flash_attn call of
+// FlashAttention.forward :46-55 computes the same function in fp16 -- here it is fp32 throughout).
+//   out[b, t, h, :] = sum_{s<=t} softmax_s(scale * q_t . k_s) v_s
+// The reference adds -10000 to the masked scores instead of excluding them; in fp32 exp(-10000 - m) is exactly 0 for
+// any row whose maximum is above -9.9e3, so the masked columns are skipped.
+// Block per (64-row t tile, head x 128-column v chunk, batch row); streams 64-wide s tiles up to the diagonal with
+// the online-softmax recurrence (running row max m, running sum l, rescaled accumulator).  Thread (ty, tx) of the
+// 16 x 16 block owns the 4 x 4 score block rows 4 ty.., columns 4 tx.. and the 4 x 8 output block rows 4 ty..,
+// columns 8 tx..; P goes through LDS transposed so that PV reads it as one float4 per s.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kAT = 64, kAD = 64, kAV = 128;
+
+__global__ __launch_bounds__(256) void softmax_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               int64_t qk_bs, int64_t qk_ts, int64_t qk_hs,
+                                                               const float* __restrict__ v, int64_t v_bs, int64_t v_ts,
+                                                               float* __restrict__ out, int64_t seqlen, int num_heads,
+                                                               int hd, int dv, float scale) {
+    // 52 KB: the V tile reuses the q/k staging area (they are dead once the score block is complete)
+    __shared__ __attribute__((aligned(16))) float smem[2 * kAD * (kAT + 4) + kAT * (kAT + 4)];
+    float (*qs)[kAT + 4] = reinterpret_cast<float (*)[kAT + 4]>(smem);                       // [d][t]
+    float (*ks)[kAT + 4] = reinterpret_cast<float (*)[kAT + 4]>(smem + kAD * (kAT + 4));     // [d][s]
+    float (*vs)[kAV + 4] = reinterpret_cast<float (*)[kAV + 4]>(smem);                       // [s][c], aliases qs | ks
+    float (*ps)[kAT + 4] = reinterpret_cast<float (*)[kAT + 4]>(smem + 2 * kAD * (kAT + 4)); // [s][t]
+    static_assert(kAT * (kAV + 4) <= 2 * kAD * (kAT + 4), "V tile must fit in the q/k staging area");
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int vchunks = (dv + kAV - 1) / kAV;
+    const int h = blockIdx.y / vchunks;
+    const int c0 = (blockIdx.y - h * vchunks) * kAV;
+    const int64_t b = blockIdx.z;
+    const int64_t t0 = (int64_t)blockIdx.x * kAT;
+    const float* qbase = q + b * qk_bs + (int64_t)h * qk_hs;
+    const float* kbase = k + b * qk_bs + (int64_t)h * qk_hs;
+    const float* vbase = v + b * v_bs + (int64_t)h * dv + c0;
+    const int cw = (dv - c0 < kAV) ? dv - c0 : kAV;                   // live columns of this chunk
+
+    float m_run[4], l_run[4], o[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m_run[i] = -INFINITY;
+        l_run[i] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[i][c] = 0.0f;
+    }
+    for (int64_t s0 = 0; s0 <= t0 + kAT - 1 && s0 < seqlen; s0 += kAT) {
+        float acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+        for (int d0 = 0; d0 < hd; d0 += kAD) {
+            __syncthreads();
+            {
+                float qv[16], kv[16];                                 // clamped addresses, zeroed by value
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int idx = tid + e * 256;
+                    const int r = idx >> 6, dd = idx & 63;
+                    const int dc = (d0 + dd < hd) ? d0 + dd : hd - 1;
+                    const int64_t tq = (t0 + r < seqlen) ? t0 + r : seqlen - 1;
+                    const int64_t sk = (s0 + r < seqlen) ? s0 + r : seqlen - 1;
+                    qv[e] = qbase[tq * qk_ts + dc];
+                    kv[e] = kbase[sk * qk_ts + dc];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int idx = tid + e * 256;
+                    const int r = idx >> 6, dd = idx & 63;
+                    const bool dok = (d0 + dd) < hd;
+                    qs[dd][r] = (dok && t0 + r < seqlen) ? qv[e] : 0.0f;
+                    ks[dd][r] = (dok && s0 + r < seqlen) ? kv[e] * scale : 0.0f;   // k * softmax_scale (:27)
+                }
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int dd = 0; dd < kAD; ++dd) {
+                const float4 a = *reinterpret_cast<const float4*>(&qs[dd][ty * 4]);
+                const float4 c = *reinterpret_cast<const float4*>(&ks[dd][tx * 4]);
+                const float av[4] = {a.x, a.y, a.z, a.w};
+                const float cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], cv[j], acc[i][j]);
+            }
+        }
+        // stage V[s0.., c0..] (64 x 128): 8192 elements, 32 per thread
+        __syncthreads();                                              // every thread is done reading qs / ks
+        {
+            float vv[32];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const int idx = tid + e * 256;
+                const int r = idx >> 7, cc = idx & 127;
+                const int64_t sk = (s0 + r < seqlen) ? s0 + r : seqlen - 1;
+                vv[e] = vbase[sk * v_ts + (cc < cw ? cc : cw - 1)];
+            }
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const int idx = tid + e * 256;
+                const int r = idx >> 7, cc = idx & 127;
+                vs[r][cc] = (cc < cw && s0 + r < seqlen) ? vv[e] : 0.0f;
+            }
+        }
+        // online softmax on the 4 x 4 block (rows shared by the 16 threads of equal ty = 16 consecutive lanes)
+        float corr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t t = t0 + ty * 4 + i;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t sidx = s0 + tx * 4 + j;
+                const bool ok = sidx <= t && sidx < seqlen;
+                acc[i][j] = ok ? acc[i][j] : -INFINITY;
+                mx = fmaxf(mx, acc[i][j]);
+            }
+            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            const float m_new = fmaxf(m_run[i], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;   // fully masked row so far
+            corr[i] = __expf(m_run[i] - m_use);                       // exp(-inf) = 0 on the first tile
+            float rs = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pij = __expf(acc[i][j] - m_use);
+                acc[i][j] = pij;
+                rs += pij;
+            }
+            for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+            l_run[i] = l_run[i] * corr[i] + rs;
+            m_run[i] = m_new;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[i][c] *= corr[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(&ps[tx * 4 + j][ty * 4]) = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
+        __syncthreads();
+#pragma unroll 4
+        for (int sl = 0; sl < kAT; ++sl) {
+            const float4 p4 = *reinterpret_cast<const float4*>(&ps[sl][ty * 4]);
+            const float4 va = *reinterpret_cast<const float4*>(&vs[sl][tx * 8]);
+            const float4 vb = *reinterpret_cast<const float4*>(&vs[sl][tx * 8 + 4]);
+            const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+            const float vc[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o[i][c] = fmaf(pv[i], vc[c], o[i][c]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = t0 + ty * 4 + i;
+        if (t < seqlen) {
+            const float inv = 1.0f / l_run[i];
+            float* dst = out + (b * seqlen + t) * ((int64_t)num_heads * dv) + (int64_t)h * dv + c0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (tx * 8 + c < cw) dst[tx * 8 + c] = o[i][c] * inv;
+        }
+    }
+}
+
+int softmax_attn_fwd_launch(const float* q, const float* k, int64_t qk_bs, int64_t qk_ts, int64_t qk_hs, const float* v,
+                            int64_t v_bs, int64_t v_ts, float* out, int64_t batch, int64_t seqlen, int num_heads,
+                            int hd, int dv, float scale, hipStream_t stream) {
+    if (batch == 0 || seqlen == 0) return 0;
+    const int vchunks = (dv + kAV - 1) / kAV;
+    const dim3 grid((unsigned)((seqlen + kAT - 1) / kAT), (unsigned)(num_heads * vchunks), (unsigned)batch);
+    hipLaunchKernelGGL(softmax_attn_fwd_kernel, grid, dim3(256), 0, stream, q, k, qk_bs, qk_ts, qk_hs, v, v_bs, v_ts, out,
+                       seqlen, num_heads, hd, dv, scale);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace egs

@@ -36,6 +36,8 @@ int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, con
                     size_t, hipStream_t);
 int threshold_hist_launch(const void*, int, int, int64_t, int64_t, int64_t, const double*, int, double*, hipStream_t);
 size_t linrec_workspace_bytes(int64_t, int64_t, int, int, int);
+int softmax_attn_fwd_launch(const float*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, float*,
+                            int64_t, int64_t, int, int, int, float, hipStream_t);
 int linrec_launch(const float*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, const float*,
                   const float*, const float*, const float*, float*, int64_t, int64_t, int, int, int, int, int, float, int,
                   void*, size_t, hipStream_t);
@@ -267,6 +269,25 @@ int egs_linear_recurrence_fwd(const float* q, const float* k, int64_t qk_batch_s
     return linrec_launch(q, k, qk_batch_stride, qk_token_stride, qk_group_stride, v, v_batch_stride, v_token_stride,
                          decay, vscale, w, skip, y, batch, seqlen, channels, d_state, cols_per_group, cols_per_decay,
                          phi, k_scale, normalise, workspace, workspace_bytes, as_stream(stream));
+}
+
+int egs_softmax_attention_fwd(const float* q, const float* k, int64_t qk_batch_stride, int64_t qk_token_stride,
+                              int64_t qk_head_stride, const float* v, int64_t v_batch_stride, int64_t v_token_stride,
+                              float* y, int64_t batch, int64_t seqlen, int num_heads, int head_dim, int v_dim,
+                              float scale, egs_stream_t stream) {
+    EGS_ARG(batch >= 0 && batch <= 65535, 10);
+    EGS_ARG(seqlen >= 0, 11);
+    EGS_ARG(num_heads > 0, 12);
+    EGS_ARG(head_dim > 0, 13);
+    EGS_ARG(v_dim > 0 && (int64_t)num_heads * ((v_dim + 127) / 128) <= 65535, 14);
+    if (batch == 0 || seqlen == 0) return 0;
+    EGS_ARG(q != nullptr, 1);
+    EGS_ARG(k != nullptr, 2);
+    EGS_ARG(v != nullptr, 6);
+    EGS_ARG(y != nullptr, 9);
+    return softmax_attn_fwd_launch(q, k, qk_batch_stride, qk_token_stride, qk_head_stride, v, v_batch_stride,
+                                   v_token_stride, y, batch, seqlen, num_heads, head_dim, v_dim, scale,
+                                   as_stream(stream));
 }
 
 }  // extern "C"

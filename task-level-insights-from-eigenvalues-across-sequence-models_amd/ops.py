@@ -292,3 +292,29 @@ def linear_recurrence_fwd(q, k, v, decay=None, vscale=None, w=None, skip=None, p
             1 if phi else 0, float(k_scale), 1 if normalise else 0, _ptr(ws), ws.numel() * ws.element_size(),
             _stream()), "egs_linear_recurrence_fwd")
     return y
+
+
+def softmax_attention_fwd(q, k, v, scale=None):
+    """Causal softmax attention, fp32: y[b,t,h,:] = sum_{s<=t} softmax_s(scale q_t.k_s) v_s.
+
+    q, k: [B, L, H, hd] views with equal strides and contiguous last dim; v: [B, L, H * dv] with contiguous channels.
+    ``scale`` defaults to 1/sqrt(hd).  Replaces SelfAttention.forward (models/attention.py:17-35)."""
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        _require_cuda(t, name)
+        if t.dtype != torch.float32:
+            raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if q.dim() != 4 or k.shape != q.shape or q.stride() != k.stride() or (q.shape[-1] > 1 and q.stride(-1) != 1):
+        raise ValueError("q and k must be [B, L, H, hd] views with identical strides and a contiguous last dim")
+    batch, seqlen, heads, hd = q.shape
+    if v.dim() != 3 or v.shape[:2] != q.shape[:2] or v.shape[-1] % heads != 0 or (v.shape[-1] > 1 and v.stride(-1) != 1):
+        raise ValueError("v must be [B, L, H * dv] with contiguous channels")
+    dv = v.shape[-1] // heads
+    y = torch.empty((batch, seqlen, heads * dv), dtype=torch.float32, device=v.device)
+    if batch == 0 or seqlen == 0:
+        return y
+    sc = float(scale) if scale is not None else 1.0 / float(hd) ** 0.5
+    with torch.cuda.device(v.device):
+        check(lib().egs_softmax_attention_fwd(_ptr(q), _ptr(k), q.stride(0), q.stride(1), q.stride(2), _ptr(v),
+                                              v.stride(0), v.stride(1), _ptr(y), batch, seqlen, heads, hd, dv, sc,
+                                              _stream()), "egs_softmax_attention_fwd")
+    return y

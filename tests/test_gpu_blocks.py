@@ -113,3 +113,41 @@ def test_linear_recurrence_argument_errors(gpu_ops):
         gpu_ops.linear_recurrence_fwd(q.double(), q.double(), v)
     empty = gpu_ops.linear_recurrence_fwd(q[:0, :, :, :8], q[:0, :, :, :8], v[:0])
     assert empty.shape == (0, 4, 8)
+
+
+def test_softmax_attention_inner_golden(gpu_ops, golden):
+    g = golden("blocks")
+    qk, v = dev(g["inner_qk"]), dev(g["inner_v"])
+    B, L, H, dv = v.shape
+    y = gpu_ops.softmax_attention_fwd(qk[:, :, 0], qk[:, :, 1], v.reshape(B, L, H * dv))
+    close(y.reshape(B, L, H, dv), g["inner_sm"])
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 1, 1, 4, 4),          # single token
+    (3, 63, 2, 8, 16),        # one partial tile
+    (2, 64, 1, 64, 128),      # exactly one tile, full v chunk
+    (1, 200, 3, 24, 40),      # several tiles, ragged head / value widths
+    (2, 130, 1, 130, 200),    # head_dim > 64 (two d chunks), v_dim > 128 (two v chunks)
+])
+def test_softmax_attention_vs_oracle(gpu_ops, shape):
+    B, L, H, hd, dv = shape
+    rng = np.random.default_rng(sum(shape))
+    qk = rng.standard_normal((B, L, 2, H, hd)).astype(np.float32)
+    v = rng.standard_normal((B, L, H, dv)).astype(np.float32)
+    want = BO.softmax_attention(qk, v)
+    t = dev(qk)
+    got = gpu_ops.softmax_attention_fwd(t[:, :, 0], t[:, :, 1], dev(v.reshape(B, L, H * dv)))
+    close(got.reshape(B, L, H, dv), want, rtol=2e-5)
+
+
+def test_softmax_attention_large_scores(gpu_ops):
+    """Scores of magnitude 1e2..1e3: the online max keeps exp() in range; rows become near one-hot."""
+    rng = np.random.default_rng(3)
+    B, L, H, hd, dv = 1, 90, 1, 16, 8
+    qk = (rng.standard_normal((B, L, 2, H, hd)) * 8).astype(np.float32)
+    v = rng.standard_normal((B, L, H, dv)).astype(np.float32)
+    want = BO.softmax_attention(qk, v)
+    t = dev(qk)
+    got = gpu_ops.softmax_attention_fwd(t[:, :, 0], t[:, :, 1], dev(v.reshape(B, L, H * dv)))
+    close(got.reshape(B, L, H, dv), want, rtol=1e-4)
