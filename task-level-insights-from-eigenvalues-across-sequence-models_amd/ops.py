@@ -247,8 +247,8 @@ def linear_recurrence_fwd(q, k, v, decay=None, vscale=None, w=None, skip=None, p
                           normalise=False, cols_per_decay=None):
     """y_t = w_t (q_t^T S_t) + skip * v_t with S_t = decay_t S_{t-1} + k_t (vscale_t v_t)^T, fp32, per batch row.
 
-    q, k: [B, L, G, d] views with equal strides and contiguous last dim (slices of a projection output are fine);
-    v: [B, L, C] with contiguous channels, C = G * cols_per_group; decay / vscale: [B, L, C // cols_per_decay];
+    q, k: [B, L, G, d] (views with equal strides and a contiguous last dim -- e.g. slices of one projection output --
+    are passed through as they are, anything else is made contiguous first); v: [B, L, C], C = G * cols_per_group; decay / vscale: [B, L, C // cols_per_decay];
     w: [B, L, G]; skip: [C].  ``normalise`` computes w_t = 1 / (q_t . sum_{s<=t} k_s) on the device instead.
     Replaces the mixers of models/attention.py:58-83, models/norm_attention.py:61-89 and the
     mamba_chunk_scan_combined calls of models/mamba.py:138-150, :276-288."""
@@ -256,11 +256,15 @@ def linear_recurrence_fwd(q, k, v, decay=None, vscale=None, w=None, skip=None, p
         _require_cuda(t, name)
         if t.dtype != torch.float32:
             raise TypeError(f"{name} must be float32, got {t.dtype}")
-    if q.dim() != 4 or k.shape != q.shape or q.stride() != k.stride() or (q.shape[-1] > 1 and q.stride(-1) != 1):
-        raise ValueError("q and k must be [B, L, G, d] views with identical strides and a contiguous last dim")
+    if q.dim() != 4 or k.shape != q.shape:
+        raise ValueError(f"q and k must both be [B, L, G, d], got {tuple(q.shape)} and {tuple(k.shape)}")
+    if q.stride() != k.stride() or (q.shape[-1] > 1 and q.stride(-1) != 1):
+        q, k = q.contiguous(), k.contiguous()                          # the ABI takes one stride triple for both
     batch, seqlen, groups, d_state = q.shape
-    if v.dim() != 3 or v.shape[:2] != q.shape[:2] or (v.shape[-1] > 1 and v.stride(-1) != 1):
-        raise ValueError("v must be [B, L, C] with contiguous channels")
+    if v.dim() != 3 or v.shape[:2] != q.shape[:2]:
+        raise ValueError(f"v must be [B, L, C] with the batch / sequence shape of q, got {tuple(v.shape)}")
+    if v.shape[-1] > 1 and v.stride(-1) != 1:
+        v = v.contiguous()
     channels = v.shape[-1]
     if channels % groups != 0:
         raise ValueError(f"channels ({channels}) must be a multiple of the q/k groups ({groups})")

@@ -108,7 +108,9 @@ def test_linear_recurrence_argument_errors(gpu_ops):
     with pytest.raises(Exception):
         gpu_ops.linear_recurrence_fwd(q, q, v)                       # d_state > 512
     with pytest.raises(ValueError):
-        gpu_ops.linear_recurrence_fwd(q[..., :8], q[..., :8], torch.zeros(1, 4, 7, device="cuda")[..., ::2])
+        gpu_ops.linear_recurrence_fwd(q[..., :8], q[..., :8], torch.zeros(2, 4, 8, device="cuda"))   # batch mismatch
+    with pytest.raises(ValueError):
+        gpu_ops.linear_recurrence_fwd(q[..., :8], q[..., :8], v, decay=torch.ones(1, 4, 3, device="cuda"))
     with pytest.raises(TypeError):
         gpu_ops.linear_recurrence_fwd(q.double(), q.double(), v)
     empty = gpu_ops.linear_recurrence_fwd(q[:0, :, :, :8], q[:0, :, :, :8], v[:0])
@@ -151,3 +153,91 @@ def test_softmax_attention_large_scores(gpu_ops):
     t = dev(qk)
     got = gpu_ops.softmax_attention_fwd(t[:, :, 0], t[:, :, 1], dev(v.reshape(B, L, H * dv)))
     close(got.reshape(B, L, H, dv), want, rtol=1e-4)
+
+
+# ---- whole models against the reference's own forward (tests/golden/blocks.npz) ------------------------------
+CASES = ["lin", "lin_conv_gate", "sm", "sm_conv", "norm_exp", "norm_softplus", "norm_sigmoid", "norm_elu"]
+
+
+def _golden_model(pkg, g, name):
+    import json
+    cfg = json.loads(bytes(g[f"{name}/cfg"]).decode())
+    keys = json.loads(bytes(g[f"{name}/keys"]).decode())
+    torch.manual_seed(0)
+    model = pkg.models.Transformer(dict(cfg))
+    assert list(model.state_dict().keys()) == keys, "parameter names / order differ from the reference's state_dict"
+    model.load_state_dict({k: torch.from_numpy(g[f"{name}/sd/{k}"]) for k in keys})
+    return cfg, model.to("cuda").eval()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_transformer_forward_matches_reference(pkg, gpu_ops, golden, name):
+    """State dict from the reference's Transformer loads by name; every block output and the logits match."""
+    g = golden("blocks")
+    cfg, model = _golden_model(pkg, g, name)
+    x = torch.from_numpy(g[f"{name}/x"]).cuda()
+    with torch.no_grad():
+        h = model.dropout(model.encoder(x))
+        close(h, g[f"{name}/h0"], rtol=1e-5)
+        for i, layer in enumerate(model.layers):
+            h = layer(h)
+            close(h, g[f"{name}/h{i + 1}"], rtol=5e-5, atol=1e-5)
+        close(model(x), g[f"{name}/y"], rtol=5e-5, atol=1e-5)
+
+
+def test_models_shim_and_seeded_init(pkg, gpu_ops, golden):
+    """`from models import Transformer` resolves to the drop-in; construction after manual_seed draws the same
+    parameters as the reference did (creation order and initialisers are mirrored): compare against the golden
+    state_dict minus the perturbation is not possible, so check determinism and the documented init values."""
+    import models as shim
+    assert shim.Transformer is pkg.models.Transformer and shim.Mamba is pkg.models.Mamba
+    with pytest.raises(ImportError):
+        shim.init_S4
+    import json
+    g = golden("blocks")
+    cfg = json.loads(bytes(g["norm_exp/cfg"]).decode())
+    torch.manual_seed(7)
+    a = shim.Transformer(dict(cfg)).state_dict()
+    torch.manual_seed(7)
+    b = shim.Transformer(dict(cfg)).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert torch.all(a["layers.0.Wz.bias"] == 1.0)                               # models/transformer.py:64
+    off = a["layers.0.attention.inner_attn.offset"]
+    assert off.shape == (cfg["num_heads"],) and float(off.min()) == 8.0 and abs(float(off.max()) - 14.0) < 1e-5
+
+
+def test_mamba_block_forward_vs_oracle(pkg, gpu_ops):
+    """Mamba-2 block: the HIP scan inside the torch block against the NumPy restatement of the SSD recurrence
+    (no golden: the reference's scan is mamba_ssm's Triton kernel)."""
+    cfg = dict(version="mamba2", num_layers=2, input_dim=5, output_dim=3, hidden_dim=32, num_heads=4, state_dim=16,
+               conv_dim=4, expansion=2, dropout=0.0, glu=True, norm="layer", prenorm=True, dual=False, pooling="none",
+               token_embedding=False)
+    for lti in (False, True):
+        torch.manual_seed(11)
+        model = pkg.models.Mamba(dict(cfg, pseudoLTI=lti)).to("cuda").eval()
+        x = torch.randn(3, 40, 5, device="cuda")
+        with torch.no_grad():
+            h = model.encoder(x)
+            blk = model.blocks[0]
+            m = blk.mamba
+            u = blk.norm(h)
+            got = m(u)
+            # restate the mixer on the host from the same projections
+            n_dt = m.ngroups if lti else m.nheads
+            xs, Bm, Cm, dt = m._split(u, n_dt)
+            xs, Bm, Cm, dt = (t.cpu().numpy() for t in (xs, Bm, Cm, dt))
+            D = m.D.detach().cpu().numpy()
+            B_, L = xs.shape[:2]
+            if lti:
+                A = -np.log1p(np.exp(m.A.detach().cpu().numpy()))
+                Bm = np.repeat(dt, m.khead_dim, axis=-1) * Bm
+                dt_eff = np.ones((B_, L, m.nheads), np.float32)
+            else:
+                A = -np.exp(m.A_log.detach().cpu().numpy())
+                dt_eff = dt
+            y = BO.ssd_scan(xs.reshape(B_, L, m.nheads, m.headdim), dt_eff, A, Bm.reshape(B_, L, m.ngroups, m.d_state),
+                            Cm.reshape(B_, L, m.ngroups, m.d_state), D).reshape(B_, L, -1)
+            want = m.out_proj(torch.from_numpy(y).cuda())
+            close(got, want.cpu().numpy(), rtol=5e-5, atol=1e-5)
+            out = model(x)
+            assert out.shape == (3, 40, 3) and bool(torch.isfinite(out).all())
