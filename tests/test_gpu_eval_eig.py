@@ -236,3 +236,82 @@ def test_eval_eig_s4_all_columns_extension(pkg, tmp_path, monkeypatch):
     for c in range(h):
         want = np.concatenate([O.eigvals_ssm("s4", trained, i, c, L) for i in range(NL)], axis=-1)
         assert O.max_abs_dlambda(cube[:, c, :].T, want.T) < 1e-5
+
+
+# ---- the drop-in torch models (`from models import Mamba, Transformer`, as the reference's eval_eig.py:24-25) ----
+def _real_transformer_cfg(attention_fn):
+    cfg = dict(layer="transformer", input_dim=1, output_dim=VOCAB, num_layers=NL, hidden_dim=D, embedding=True,
+               vocab_size=VOCAB, max_pos_embed=0, pooling="none", dual=False, classifier=False, mixer_dim=24,
+               norm="layer", dropout=0.1, state_dim=DQK, num_heads=H, att_dropout=0.0, mixer="mlp", use_flash=False,
+               attention_fn=attention_fn, dim_conv=3, seq_len=L)
+    if attention_fn == "norm-attention":
+        cfg.update(mode="attention", norm_fn="softplus", approx_fn="elu", scale_B=True, offset=True,
+                   offset_init="uniform", learn_A=False)
+    return cfg
+
+
+@pytest.mark.parametrize("attention_fn", ["sm-attention", "lin-attention", "norm-attention"])
+def test_eval_eig_with_dropin_transformer(pkg, tmp_path, monkeypatch, attention_fn):
+    """No model_classes override: eval_eig imports Transformer from ``models`` like the reference does, builds it
+    from the YAML-style config, loads the .pth checkpoint by parameter name and forwards through the HIP mixers."""
+    monkeypatch.chdir(tmp_path)
+    os.mkdir(tmp_path / "results")
+    cfg = _real_transformer_cfg(attention_fn)
+    args = {"model": cfg, "train": {"lr": 0.01}, "dataset": {"name": "TOY"}, "seed": 1919}
+    torch.manual_seed(3)
+    trained = pkg.models.Transformer({k: v for k, v in cfg.items() if k != "layer"})
+    with torch.no_grad():
+        for p in trained.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    torch.save(trained.state_dict(), tmp_path / "ckpt.pth")
+    conf = {"batch_size": B, "save_path": str(tmp_path / "results") + "/"}
+    loader = _loader()
+    eig, eig_init, pct, pct_init, _, _ = pkg.eval_eig(copy.deepcopy(args), conf, None, None, loader, "ckpt.pth", 0.9)
+    assert eig.shape == eig_init.shape == (B, L - 1, H, NL)
+    assert not np.allclose(eig, eig_init)                          # init weights (seed 1919) vs the checkpoint
+
+    trained = trained.cuda().eval()
+    xs = _block_outputs(trained, trained.layers, loader[0][0])
+    want = []
+    for x, layer in zip(xs, trained.layers):
+        att = layer.attention
+        if attention_fn == "sm-attention":
+            want.append(O.eta_softmax(x, _np(att.Wqkv.weight), _np(att.Wqkv.bias), DQK, H, D))
+        elif attention_fn == "lin-attention":
+            want.append(O.eta_linear(x, _np(att.Wqkv.weight), _np(att.Wqkv.bias), DQK, H, D))
+        else:
+            want.append(O.eta_norm(x, _np(att.Wvqkn.weight), _np(att.Wvqkn.bias), _np(att.inner_attn.offset),
+                                   "softplus", DQK, H, D))
+    np.testing.assert_allclose(eig, np.concatenate(want, axis=-1), rtol=5e-5)
+    np.testing.assert_array_equal(pct, O.threshold_analysis(eig, O.THRESHOLDS_RADIUS, NL, H, B))
+    assert sorted(os.listdir(tmp_path / "results"))                # artefacts were written
+
+
+@pytest.mark.parametrize("pseudo_lti", [False, True])
+def test_eval_eig_with_dropin_mamba(pkg, tmp_path, monkeypatch, pseudo_lti):
+    monkeypatch.chdir(tmp_path)
+    os.mkdir(tmp_path / "results")
+    nheads = 4
+    cfg = dict(layer="mamba", version="mamba2", num_layers=NL, input_dim=1, output_dim=VOCAB, hidden_dim=D,
+               num_heads=nheads, state_dim=8, conv_dim=4, expansion=1, dropout=0.0, glu=True, norm="layer", prenorm=True,
+               dual=False, pooling="none", token_embedding=True, vocab_size=VOCAB, pseudoLTI=pseudo_lti, seq_len=L)
+    args = {"model": cfg, "train": {"lr": 0.01}, "dataset": {"name": "TOY"}, "seed": 1919}
+    torch.manual_seed(5)
+    trained = pkg.models.Mamba({k: v for k, v in cfg.items() if k != "layer"})
+    torch.save(trained.state_dict(), tmp_path / "ckpt.pth")
+    conf = {"batch_size": B, "save_path": str(tmp_path / "results") + "/"}
+    loader = _loader()
+    eig, eig_init, pct, _, pct_phase, _ = pkg.eval_eig(copy.deepcopy(args), conf, None, None, loader, "ckpt.pth", 0.9)
+    m0 = trained.blocks[0].mamba
+    assert eig.shape == (B, L, m0.nheads, NL) and eig.dtype == np.float32
+    trained = trained.cuda().eval()
+    xs = _block_outputs(trained, trained.blocks, loader[0][0])
+    want = []
+    for x, blk in zip(xs, trained.blocks):
+        m = blk.mamba
+        if pseudo_lti:
+            want.append(O.lambda_mamba2_lti(x, _np(m.A), _np(m.beta)))
+        else:
+            want.append(O.lambda_mamba2(x, _np(m.in_proj.weight), None, _np(m.dt_bias), _np(m.A_log), m.d_inner,
+                                        m.ngroups, m.d_state, m.nheads))
+    np.testing.assert_allclose(eig, np.concatenate(want, axis=-1), rtol=2e-5)
