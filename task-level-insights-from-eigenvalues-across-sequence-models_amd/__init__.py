@@ -7,6 +7,7 @@ Layout
   ops.py           thin device-tensor wrappers (torch is used for device memory / streams only)
   dist.py          batch sharding across ranks + the single all-gather of spectra
   analysis/        host-side mirror of the reference's ``analysis`` package (same names / signatures)
+  ckpt.py          orbax aggregate-file (msgpack) checkpoint decoder, no JAX needed
   models.py        drop-in torch ``models`` (Transformer / Mamba) whose token mixers run in the HIP library
 
 The directory name contains hyphens; import it with
@@ -15,6 +16,7 @@ The directory name contains hyphens; import it with
 from . import _capi  # noqa: F401
 from . import ops  # noqa: F401
 from . import dist  # noqa: F401
+from . import ckpt  # noqa: F401
 from . import models  # noqa: F401
 from .analysis import eval_eig  # noqa: F401
 

@@ -283,8 +283,8 @@ def _hippo_dplr(n):
 
 def get_trained_layers_ssm(path):
     """Per-layer trained SSM parameter sub-trees (eval_eig.py:241-252).  An orbax checkpoint directory is restored
-    with orbax (as the reference does); a ``.npz`` file with keys ``encoder/layers_<i>/seq/<name>`` is read directly
-    (interchange format for environments without orbax)."""
+    with orbax when it is installed (as the reference does) and otherwise decoded from its aggregate msgpack file
+    (ckpt.read_aggregate); a ``.npz`` file with keys ``encoder/layers_<i>/seq/<name>`` is read directly."""
     if str(path).endswith(".npz"):
         flat = np.load(path, allow_pickle=False)
         params = {"encoder": {}}
@@ -295,8 +295,15 @@ def get_trained_layers_ssm(path):
         ordered = sorted(params["encoder"], key=lambda s: int(s.split("_")[-1]))
         params["encoder"] = {k: params["encoder"][k] for k in ordered}
         return _seq_params(params)
-    import orbax.checkpoint as ocp
-    raw = ocp.PyTreeCheckpointer().restore(path)
+    try:
+        import orbax.checkpoint as ocp
+    except ImportError:
+        # no orbax on this machine: decode the aggregate msgpack file the reference's save_model writes
+        # (jax_helpers/train_helpers.py:395-409) directly
+        from .. import ckpt
+        raw = ckpt.read_aggregate(path)
+    else:
+        raw = ocp.PyTreeCheckpointer().restore(path)
     return _seq_params(raw["model"]["params"])
 
 

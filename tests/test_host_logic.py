@@ -228,3 +228,60 @@ def test_cpu_baseline_script_runs(tmp_path):
                           "--block", "16"], capture_output=True, text=True, timeout=120)
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["cores"] == 2 and rec["value"] > 0 and rec["kind"] == "port"
+
+
+# ---- checkpoint decoding without orbax --------------------------------------------------
+def _fake_train_state(rng, layers=3):
+    enc = {"encoder": {"kernel": rng.standard_normal((4, 8)).astype(np.float32), "bias": np.zeros(8, np.float32)}}
+    for i in range(layers):
+        enc[f"layers_{i}"] = {"seq": {"Lambda_re": rng.standard_normal(6).astype(np.float32),
+                                      "Lambda_im": rng.standard_normal(6).astype(np.float32),
+                                      "log_step": rng.standard_normal((6, 1)).astype(np.float32),
+                                      "B": (rng.standard_normal((6, 8, 2))).astype(np.float32)},
+                              "norm": {"scale": np.ones(8, np.float32)}}
+    return {"model": {"params": {"encoder": enc, "decoder": {"kernel": rng.standard_normal((8, 2)).astype(np.float32)}},
+                      "step": np.int32(1200), "opt_state": {"count": np.array(7, np.int32)}},
+            "config": {"lr": 0.004, "name": "s5", "flag": True, "phase": 1 + 2j}}
+
+
+def test_orbax_aggregate_checkpoint_roundtrip(pkg, tmp_path):
+    """The layout ocp.PyTreeCheckpointer writes for flax's save_args_from_target (one msgpack 'checkpoint' file, flax
+    ext types) decodes to the same tree; get_trained_layers_ssm finds model/params/encoder/layers_i/seq in it."""
+    rng = np.random.default_rng(0)
+    tree = _fake_train_state(rng)
+    ck = str(tmp_path / "ckpt_dir")
+    pkg.ckpt.write_aggregate(ck, tree)
+    back = pkg.ckpt.read_aggregate(ck)
+    np.testing.assert_array_equal(back["model"]["params"]["encoder"]["layers_1"]["seq"]["B"],
+                                  tree["model"]["params"]["encoder"]["layers_1"]["seq"]["B"])
+    assert back["model"]["step"] == 1200 and back["config"]["phase"] == 1 + 2j and back["config"]["flag"] is True
+    layers = sys.modules[pkg.__name__ + ".analysis.eval_eig"].get_trained_layers_ssm(ck)
+    assert len(layers) == 3
+    for i, lay in enumerate(layers):
+        np.testing.assert_array_equal(lay["Lambda_re"], tree["model"]["params"]["encoder"][f"layers_{i}"]["seq"]["Lambda_re"])
+
+
+def test_orbax_aggregate_known_bytes(pkg, tmp_path):
+    """Known-answer check of the ndarray ext encoding: msgpack ext type 1 wrapping msgpack((shape, dtype, bytes))."""
+    import msgpack
+    arr = np.arange(6, dtype="<f4").reshape(2, 3)
+    inner = msgpack.packb(([2, 3], "float32", arr.tobytes()), use_bin_type=True)
+    blob = msgpack.packb({"a": msgpack.ExtType(1, inner), "n": msgpack.ExtType(3, msgpack.packb(([], "int64", np.int64(5).tobytes()), use_bin_type=True))},
+                         use_bin_type=True)
+    f = tmp_path / "checkpoint"
+    f.write_bytes(blob)
+    tree = pkg.ckpt.read_aggregate(str(tmp_path))
+    np.testing.assert_array_equal(tree["a"], arr)
+    assert tree["n"] == 5 and tree["a"].dtype == np.float32
+
+
+def test_orbax_chunked_arrays_and_placeholders(pkg, tmp_path):
+    big = np.arange(10, dtype=np.float64)
+    tree = {"w": {"__msgpack_chunked_array__": True, "shape": [2, 5], "chunks": {"0": big[:4], "1": big[4:]}}}
+    pkg.ckpt.write_aggregate(str(tmp_path / "c1"), tree)
+    np.testing.assert_array_equal(pkg.ckpt.read_aggregate(str(tmp_path / "c1"))["w"], big.reshape(2, 5))
+    pkg.ckpt.write_aggregate(str(tmp_path / "c2"), {"model": {"params": {"k": "PLACEHOLDER://model.params.k"}}})
+    with pytest.raises(NotImplementedError):
+        pkg.ckpt.read_aggregate(str(tmp_path / "c2"))
+    with pytest.raises(FileNotFoundError):
+        pkg.ckpt.read_aggregate(str(tmp_path / "nothing_here"))
