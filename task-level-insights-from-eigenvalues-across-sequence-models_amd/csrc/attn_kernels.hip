@@ -512,6 +512,177 @@ __global__ __launch_bounds__(256) void softmax_nu_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 2c. the same two-pass row statistics with the score tiles on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32
+//     products and sums).  Workgroup = 4 waves = 64 query rows (16 per wave) of one (b, h); key blocks of 64 up to
+//     the diagonal, staged once per block in LDS for all four waves.  Each wave computes TRANSPOSED score tiles
+//     D[s][t] = K_tile . Q_tile^T: lane l then owns query row t = l % 16 for every tile, so the row maximum / row sum
+//     are in-lane reductions over the accumulator registers plus one 2-step combine of the four lane groups at the end.
+//       A operand (16 x 4):  lane l -> K[s0 + l % 16][4 j + l / 16]   (LDS, layout [d % 4][s][d / 4]: one 16-byte read
+//                                                                      feeds 4 MFMAs, conflict-free with a 4-float pad)
+//       B operand (4 x 16):  lane l -> Q[t0 + l % 16][4 j + l / 16]   (J registers, loaded once per workgroup)
+//       D (16 x 16, 4 regs): lane l, reg r -> score(s = s0 + 4 (l / 16) + r, t = t0 + l % 16)
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kNuRows = 64;
+
+// exp(x) in fp64 for the fp32 differences of eval_eig.py:72-77: 2^n * exp(r), r = x - n ln2 in [-0.35, 0.35], degree-11
+// Taylor polynomial (truncation 4e-15 relative) -- a quarter of the instructions of the general-purpose routine, which
+// matters because pass 2 evaluates it once per score element.  Arguments below -745 give 0 like exp() does.
+__device__ __forceinline__ double exp_f64_fast(double x) {
+    if (!(x > -745.0)) return (x == x) ? 0.0 : x;                     // underflow; NaN propagates
+    const double n = rint(x * 1.4426950408889634);
+    const double r = fma(n, -6.93147180369123816490e-01, x) - n * 1.90821492927058770002e-10;   // ln2 hi / lo
+    double p = 2.50521083854417187751e-08;                            // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);
+    p = fma(p, r, 2.75573192239858906526e-06);
+    p = fma(p, r, 2.48015873015873015873e-05);
+    p = fma(p, r, 1.98412698412698412698e-04);
+    p = fma(p, r, 1.38888888888888888889e-03);
+    p = fma(p, r, 8.33333333333333333333e-03);
+    p = fma(p, r, 4.16666666666666666667e-02);
+    p = fma(p, r, 1.66666666666666666667e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+template <int J, int KB>
+__global__ __launch_bounds__(256) void softmax_nu_mfma_kernel(const float* __restrict__ qk, int64_t seqlen, int d_qk,
+                                                              int num_heads, double* __restrict__ nu,
+                                                              float* __restrict__ mrow) {
+    extern __shared__ __attribute__((aligned(16))) float ks2[];      // [4][KB][J + 4]
+    constexpr int kLd = J + 4;
+    constexpr int kV4 = (KB * J + 255) / 256;                         // float4 of the K block per thread
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int h = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int hd = d_qk / num_heads;                                  // multiple of 4 (checked by the launcher)
+    const int64_t t0 = (int64_t)blockIdx.x * kNuRows;
+    const float* qbase = qk + b * seqlen * 2 * d_qk + (int64_t)h * hd;
+    const float* kbase = qbase + d_qk;
+    const int64_t t = t0 + 16 * w + c;                                // this lane's query row
+    const int64_t tc = t < seqlen ? t : seqlen - 1;
+
+    float qreg[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int d = 4 * j + g;
+        const float v = qbase[tc * 2 * d_qk + (d < hd ? d : hd - 1)];
+        qreg[j] = (d < hd && t < seqlen) ? v : 0.0f;
+    }
+    const int64_t wave_tmax = t0 + 16 * w + 15;                       // last query row of this wave
+    const int64_t s_end = (t0 + kNuRows < seqlen) ? t0 + kNuRows : seqlen;   // keys [0, s_end) are needed
+
+    // K block of keys s0..s0+KB-1 as kV4 float4 per thread (key sr, dims 4 j..4 j+3), fetched a block ahead
+    float4 kpre[kV4];
+    auto fetch = [&](int64_t s0) {
+#pragma unroll
+        for (int x = 0; x < kV4; ++x) {
+            const int idx = tid + 256 * x;
+            const int sr = (idx / J) % KB, j = idx % J;
+            const int64_t sk = (s0 + sr < seqlen) ? s0 + sr : seqlen - 1;
+            const int dj = (4 * j < hd) ? 4 * j : hd - 4;
+            kpre[x] = *reinterpret_cast<const float4*>(kbase + sk * 2 * d_qk + dj);
+        }
+    };
+    fetch(0);
+
+    float m_run = -INFINITY;
+    double sum_run = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int64_t s0 = 0; s0 < s_end; s0 += KB) {
+            __syncthreads();                                          // previous block fully consumed
+#pragma unroll
+            for (int x = 0; x < kV4; ++x) {
+                const int idx = tid + 256 * x;
+                const int sr = idx / J, j = idx - sr * J;
+                if (idx < KB * J) {
+                    const bool ok = (4 * j < hd) && (s0 + sr < seqlen);
+                    ks2[(0 * KB + sr) * kLd + j] = ok ? kpre[x].x : 0.0f;
+                    ks2[(1 * KB + sr) * kLd + j] = ok ? kpre[x].y : 0.0f;
+                    ks2[(2 * KB + sr) * kLd + j] = ok ? kpre[x].z : 0.0f;
+                    ks2[(3 * KB + sr) * kLd + j] = ok ? kpre[x].w : 0.0f;
+                }
+            }
+            __syncthreads();
+            {                                                         // next block (or the first one of pass 2)
+                const int64_t sn = (s0 + KB < s_end) ? s0 + KB : 0;
+                fetch(sn);
+            }
+            // four score tiles (64 keys) at a time: independent accumulator chains keep the matrix pipe busy
+#pragma unroll
+            for (int tq = 0; tq < KB / 16; tq += 4) {
+                if (s0 + 16 * tq > wave_tmax) continue;               // wave-uniform: all four tiles above the diagonal
+                f32x4 acc[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] = {0.0f, 0.0f, 0.0f, 0.0f};
+                const float* kr = ks2 + (g * KB + 16 * tq + c) * kLd;
+#pragma unroll
+                for (int jj = 0; jj < J; jj += 4) {
+                    float4 k4[4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) k4[x] = *reinterpret_cast<const float4*>(kr + 16 * x * kLd + jj);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].x, qreg[jj], acc[x], 0, 0, 0);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].y, qreg[jj + 1], acc[x], 0, 0, 0);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].z, qreg[jj + 2], acc[x], 0, 0, 0);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].w, qreg[jj + 3], acc[x], 0, 0, 0);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float sc[4] = {acc[x].x, acc[x].y, acc[x].z, acc[x].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t sidx = s0 + 16 * (tq + x) + 4 * g + r;
+                        const bool ok = sidx <= t && t < seqlen;
+                        if (pass == 0) {
+                            m_run = ok ? fmaxf(m_run, sc[r]) : m_run;
+                        } else if (ok) {
+                            const float diff = __fsub_rn(sc[r], m_run);   // fp32, eval_eig.py:72
+                            const double e = exp_f64_fast((double)diff);  // :74-77
+                            sum_run += (e == e) ? e : 0.0;                // nan_to_num
+                        }
+                    }
+                }
+            }
+        }
+        if (pass == 0) {
+            m_run = fmaxf(m_run, __shfl_xor(m_run, 16, 64));
+            m_run = fmaxf(m_run, __shfl_xor(m_run, 32, 64));
+            // zero-masked entries s > t take part in the row max (quirk Q5): present unless t == L-1
+            if (t < seqlen - 1) m_run = fmaxf(m_run, 0.0f);
+        }
+    }
+    sum_run += __shfl_xor(sum_run, 16, 64);
+    sum_run += __shfl_xor(sum_run, 32, 64);
+    if (g == 0 && t < seqlen) {
+        const int64_t o = (b * num_heads + h) * seqlen + t;
+        nu[o] = sum_run + (double)(seqlen - 1 - t);                   // masked entries contribute exp(0) = 1 each (Q4)
+        mrow[o] = m_run;
+    }
+}
+
+// key block per LDS stage
+template <int J>
+static int softmax_nu_mfma_launch(const float* qk, int64_t nb, int64_t seqlen, int d_qk, int num_heads, double* nu,
+                                  float* mrow, hipStream_t stream) {
+    constexpr int KB = 64;   // measured: 128- and 256-key stages are 8-12 % slower (occupancy, loads past the diagonal)
+    const size_t dyn = (size_t)4 * KB * (J + 4) * sizeof(float);
+    if (dyn > 48 * 1024)
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_nu_mfma_kernel<J, KB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    const dim3 grid((unsigned)((seqlen + kNuRows - 1) / kNuRows), (unsigned)num_heads, (unsigned)nb);
+    hipLaunchKernelGGL((softmax_nu_mfma_kernel<J, KB>), grid, dim3(256), dyn, stream, qk, seqlen, d_qk, num_heads, nu,
+                       mrow);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3. eta[b, t, h] from nu[b, h, t] (and m[b, h, t] for softmax)
 // ---------------------------------------------------------------------------------------------------
 __global__ void eta_finalize_kernel(const double* __restrict__ nu, const float* __restrict__ mrow, int64_t nseq,
@@ -631,8 +802,19 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
                                n_cols, qk);
         EGS_LAUNCH_CHECK();
         if (softmax) {
-            const dim3 sgrid((unsigned)((seqlen + kTT - 1) / kTT), (unsigned)num_heads, (unsigned)nb);
-            hipLaunchKernelGGL(softmax_nu_kernel, sgrid, dim3(256), 0, stream, qk, seqlen, d_qk, num_heads, nu, mrow);
+            const int hd4 = (hd + 3) / 4;
+            if (hd % 4 == 0 && d_qk % 4 == 0 && hd4 <= 64 && !getenv("EGS_SOFTMAX_VALU")) {   // matrix-core tiles
+                int st = 0;
+                if (hd4 <= 4) st = softmax_nu_mfma_launch<4>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+                else if (hd4 <= 8) st = softmax_nu_mfma_launch<8>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+                else if (hd4 <= 16) st = softmax_nu_mfma_launch<16>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+                else if (hd4 <= 32) st = softmax_nu_mfma_launch<32>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+                else st = softmax_nu_mfma_launch<64>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+                if (st) return st;
+            } else {
+                const dim3 sgrid((unsigned)((seqlen + kTT - 1) / kTT), (unsigned)num_heads, (unsigned)nb);
+                hipLaunchKernelGGL(softmax_nu_kernel, sgrid, dim3(256), 0, stream, qk, seqlen, d_qk, num_heads, nu, mrow);
+            }
         } else {
             const int64_t tasks = nb * num_heads * nchunks;
             const unsigned grid = (unsigned)((tasks + 3) / 4);

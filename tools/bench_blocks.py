@@ -33,8 +33,21 @@ def main():
         ("mamba2 C3-like 1024x2048 D=128 N=16 4 heads", 1024, 2048, 1, 16, 128, 32, True),
         ("mamba2 512x1024 D=256 N=64 8 heads", 512, 1024, 1, 64, 256, 32, True),
     ]
+    sm_cases = [
+        # name, B, L, H, hd, dv
+        ("softmax-attn MQAR 64x512 D=128 d_qk=128 H=1", 64, 512, 1, 128, 128),
+        ("softmax-attn 4096x512 D=128 d_qk=128 H=1", 4096, 512, 1, 128, 128),
+        ("softmax-attn 64x1024 D=512 H=8 hd=64", 64, 1024, 8, 64, 64),
+    ]
     if len(sys.argv) > 1:
         cases = [c for c in cases if sys.argv[1] in c[0]]
+        sm_cases = [c for c in sm_cases if sys.argv[1] in c[0]]
+    for name, B, L, H, hd, dv in sm_cases:
+        qk = torch.randn(B, L, 2, H, hd, device="cuda")
+        v = torch.randn(B, L, H * dv, device="cuda")
+        ms = timeit(lambda: ops.softmax_attention_fwd(qk[:, :, 0], qk[:, :, 1], v))
+        flops = B * H * L * (L + 1) / 2 * (hd + dv) * 2
+        print(json.dumps({"case": name, "ms": ms, "tflops_causal": flops / ms / 1e9}), flush=True)
     for name, B, L, G, d, cpg, cpd, decay in cases:
         C = G * cpg
         q = torch.randn(B, L, G, d, device="cuda") / d ** 0.5
