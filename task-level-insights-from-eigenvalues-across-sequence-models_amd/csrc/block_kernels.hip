@@ -651,10 +651,230 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same forward on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32), used when head_dim % 4 == 0 and the rows
+// are 16-byte aligned.  Workgroup = 4 waves = 64 query rows (16 per wave); 64-key blocks up to the diagonal, K and V
+// staged once per block for all four waves and fetched a block ahead.  Scores are computed TRANSPOSED,
+// D[s][t] = K_tile . Q_tile^T, so lane l owns query row t = l % 16: the online-softmax statistics are in-lane, and an
+// accumulator register of the probability tile -- P[s = 16 x + 4 (l/16) + r][t] -- is directly the A operand
+// (m = t, k = l / 16) of the P V product for the key subset {16 x + 4 g + r}; the B operand is V[that key][column].
+// The output accumulators are in the D layout (row 4 (l/16) + r, column l % 16); the per-row rescale factors reach
+// them with 4 lane shuffles per block.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int J, int NT>
+__global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, int64_t qk_bs, int64_t qk_ts, int64_t qk_hs,
+    const float* __restrict__ v, int64_t v_bs, int64_t v_ts, float* __restrict__ out, int64_t seqlen, int num_heads,
+    int hd, int dv, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    constexpr int kLd = J + 4;                                        // K stage: [4][64][J + 4]
+    constexpr int kLv = NT * 16 + 4;                                  // V stage: [64][NT * 16 + 4]
+    constexpr int kK4 = (64 * J) / 256;                               // float4 of the K block per thread
+    constexpr int kV4 = (64 * NT * 4) / 256;                          // float4 of the V block per thread (= NT)
+    float* ks2 = fsm;
+    float* vs = fsm + 4 * 64 * kLd;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int vchunks = (dv + NT * 16 - 1) / (NT * 16);
+    const int h = blockIdx.y / vchunks;
+    const int c0 = (blockIdx.y - h * vchunks) * (NT * 16);
+    const int cw = (dv - c0 < NT * 16) ? dv - c0 : NT * 16;           // live columns of this chunk
+    const int64_t b = blockIdx.z;
+    const int64_t t0 = (int64_t)blockIdx.x * 64;
+    const float* qbase = q + b * qk_bs + (int64_t)h * qk_hs;
+    const float* kbase = k + b * qk_bs + (int64_t)h * qk_hs;
+    const float* vbase = v + b * v_bs + (int64_t)h * dv + c0;
+    const int64_t t = t0 + 16 * w + c;                                // this lane's query row
+    const int64_t tc = t < seqlen ? t : seqlen - 1;
+
+    float qreg[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int d = 4 * j + g;
+        const float x = qbase[tc * qk_ts + (d < hd ? d : hd - 1)];
+        qreg[j] = (d < hd && t < seqlen) ? x * scale : 0.0f;           // softmax_scale folded into q (:26-27)
+    }
+    const int64_t wave_tmax = t0 + 16 * w + 15;
+    const int64_t s_end = (t0 + 64 < seqlen) ? t0 + 64 : seqlen;
+
+    float4 kpre[kK4], vpre[kV4];
+    auto fetch = [&](int64_t s0) {
+#pragma unroll
+        for (int x = 0; x < kK4; ++x) {
+            const int idx = tid + 256 * x;
+            const int sr = idx / J, j = idx - sr * J;
+            const int64_t sk = (s0 + sr < seqlen) ? s0 + sr : seqlen - 1;
+            kpre[x] = *reinterpret_cast<const float4*>(kbase + sk * qk_ts + ((4 * j < hd) ? 4 * j : hd - 4));
+        }
+#pragma unroll
+        for (int x = 0; x < kV4; ++x) {
+            const int idx = tid + 256 * x;
+            const int sr = idx / (NT * 4), j = idx - sr * (NT * 4);
+            const int64_t sk = (s0 + sr < seqlen) ? s0 + sr : seqlen - 1;
+            const float* src = vbase + sk * v_ts;
+            float e[4];
+#pragma unroll
+            for (int y = 0; y < 4; ++y) e[y] = src[(4 * j + y < cw) ? 4 * j + y : cw - 1];   // v rows need not be aligned
+            vpre[x] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    };
+    fetch(0);
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x4 o[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o[nt] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int64_t s0 = 0; s0 < s_end; s0 += 64) {
+        __syncthreads();                                              // previous block fully consumed
+#pragma unroll
+        for (int x = 0; x < kK4; ++x) {
+            const int idx = tid + 256 * x;
+            const int sr = idx / J, j = idx - sr * J;
+            const bool ok = (4 * j < hd) && (s0 + sr < seqlen);
+            ks2[(0 * 64 + sr) * kLd + j] = ok ? kpre[x].x : 0.0f;
+            ks2[(1 * 64 + sr) * kLd + j] = ok ? kpre[x].y : 0.0f;
+            ks2[(2 * 64 + sr) * kLd + j] = ok ? kpre[x].z : 0.0f;
+            ks2[(3 * 64 + sr) * kLd + j] = ok ? kpre[x].w : 0.0f;
+        }
+#pragma unroll
+        for (int x = 0; x < kV4; ++x) {
+            const int idx = tid + 256 * x;
+            const int sr = idx / (NT * 4), j = idx - sr * (NT * 4);
+            const bool rok = s0 + sr < seqlen;
+            float4 val = vpre[x];
+            val.x = (rok && 4 * j + 0 < cw) ? val.x : 0.0f;
+            val.y = (rok && 4 * j + 1 < cw) ? val.y : 0.0f;
+            val.z = (rok && 4 * j + 2 < cw) ? val.z : 0.0f;
+            val.w = (rok && 4 * j + 3 < cw) ? val.w : 0.0f;
+            *reinterpret_cast<float4*>(vs + sr * kLv + 4 * j) = val;
+        }
+        __syncthreads();
+        fetch((s0 + 64 < s_end) ? s0 + 64 : 0);
+        if (s0 > wave_tmax) continue;                                 // wave-uniform: whole block above this wave's rows
+
+        f32x4 acc[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[x] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* kr = ks2 + (g * 64 + c) * kLd;
+#pragma unroll
+        for (int jj = 0; jj < J; jj += 4) {
+            float4 k4[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) k4[x] = *reinterpret_cast<const float4*>(kr + 16 * x * kLd + jj);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].x, qreg[jj], acc[x], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].y, qreg[jj + 1], acc[x], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].z, qreg[jj + 2], acc[x], 0, 0, 0);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].w, qreg[jj + 3], acc[x], 0, 0, 0);
+        }
+        // online softmax for row t (this lane's 16 of the block's 64 keys; the other 48 sit in the other lane groups)
+        float p[4][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float sc[4] = {acc[x].x, acc[x].y, acc[x].z, acc[x].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t sidx = s0 + 16 * x + 4 * g + r;
+                const bool ok = sidx <= t && sidx < seqlen;
+                p[x][r] = ok ? sc[r] : -INFINITY;
+                mx = fmaxf(mx, p[x][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;      // fully masked so far (rows past the end)
+        const float corr = __expf(m_run - m_use);                     // exp(-inf) = 0 on the first block
+        float rs = 0.0f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[x][r] = __expf(p[x][r] - m_use);
+                rs += p[x][r];
+            }
+        l_run = l_run * corr + rs;
+        m_run = m_new;
+        // rescale the output rows 4 g + r with the factor of query row 4 g + r (held by lane 4 g + r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float cr = __shfl(corr, 4 * g + r, 64);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) o[nt][r] *= cr;
+        }
+        // P V:  A = P^T register (x, r) -> keys 16 x + 4 g + r;  B = V[key][16 nt + c]
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vr = vs + (16 * x + 4 * g + r) * kLv + c;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[x][r], vr[16 * nt], o[nt], 0, 0, 0);
+            }
+        }
+    }
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float ir = __shfl(inv, 4 * g + r, 64);
+        const int64_t trow = t0 + 16 * w + 4 * g + r;
+        if (trow < seqlen) {
+            float* dst = out + (b * seqlen + trow) * ((int64_t)num_heads * dv) + (int64_t)h * dv + c0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (16 * nt + c < cw) dst[16 * nt + c] = o[nt][r] * ir;
+        }
+    }
+}
+
+template <int J, int NT>
+static int softmax_attn_fwd_mfma_launch(const float* q, const float* k, int64_t qk_bs, int64_t qk_ts, int64_t qk_hs,
+                                        const float* v, int64_t v_bs, int64_t v_ts, float* out, int64_t batch,
+                                        int64_t seqlen, int num_heads, int hd, int dv, float scale, hipStream_t stream) {
+    const size_t dyn = ((size_t)4 * 64 * (J + 4) + (size_t)64 * (NT * 16 + 4)) * sizeof(float);
+    if (dyn > 48 * 1024)
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_attn_fwd_mfma_kernel<J, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    const int vchunks = (dv + NT * 16 - 1) / (NT * 16);
+    const dim3 grid((unsigned)((seqlen + 63) / 64), (unsigned)(num_heads * vchunks), (unsigned)batch);
+    hipLaunchKernelGGL((softmax_attn_fwd_mfma_kernel<J, NT>), grid, dim3(256), dyn, stream, q, k, qk_bs, qk_ts, qk_hs, v,
+                       v_bs, v_ts, out, seqlen, num_heads, hd, dv, scale);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
 int softmax_attn_fwd_launch(const float* q, const float* k, int64_t qk_bs, int64_t qk_ts, int64_t qk_hs, const float* v,
                             int64_t v_bs, int64_t v_ts, float* out, int64_t batch, int64_t seqlen, int num_heads,
                             int hd, int dv, float scale, hipStream_t stream) {
     if (batch == 0 || seqlen == 0) return 0;
+    const bool aligned = hd % 4 == 0 && qk_bs % 4 == 0 && qk_ts % 4 == 0 && qk_hs % 4 == 0 &&
+                         reinterpret_cast<uintptr_t>(q) % 16 == 0 && reinterpret_cast<uintptr_t>(k) % 16 == 0;
+    if (aligned && hd <= 256 && !getenv("EGS_SOFTMAX_VALU")) {        // matrix-core path
+#define EGS_FA_ARGS q, k, qk_bs, qk_ts, qk_hs, v, v_bs, v_ts, out, batch, seqlen, num_heads, hd, dv, scale, stream
+#define EGS_FA_NT(JV)                                                                   \
+    return dv <= 16   ? softmax_attn_fwd_mfma_launch<JV, 1>(EGS_FA_ARGS)                \
+           : dv <= 32 ? softmax_attn_fwd_mfma_launch<JV, 2>(EGS_FA_ARGS)                \
+           : dv <= 64 ? softmax_attn_fwd_mfma_launch<JV, 4>(EGS_FA_ARGS)                \
+                      : softmax_attn_fwd_mfma_launch<JV, 8>(EGS_FA_ARGS);
+        const int hd4 = hd / 4;
+        if (hd4 <= 4) { EGS_FA_NT(4) }
+        if (hd4 <= 8) { EGS_FA_NT(8) }
+        if (hd4 <= 16) { EGS_FA_NT(16) }
+        if (hd4 <= 32) { EGS_FA_NT(32) }
+        EGS_FA_NT(64)
+#undef EGS_FA_NT
+#undef EGS_FA_ARGS
+    }
     const int vchunks = (dv + kAV - 1) / kAV;
     const dim3 grid((unsigned)((seqlen + kAT - 1) / kAT), (unsigned)(num_heads * vchunks), (unsigned)batch);
     hipLaunchKernelGGL(softmax_attn_fwd_kernel, grid, dim3(256), 0, stream, q, k, qk_bs, qk_ts, qk_hs, v, v_bs, v_ts, out,

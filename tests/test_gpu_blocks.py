@@ -241,3 +241,17 @@ def test_mamba_block_forward_vs_oracle(pkg, gpu_ops):
             close(got, want.cpu().numpy(), rtol=5e-5, atol=1e-5)
             out = model(x)
             assert out.shape == (3, 40, 3) and bool(torch.isfinite(out).all())
+
+
+def test_softmax_attention_mfma_and_valu_paths_agree(gpu_ops, monkeypatch):
+    """The matrix-core kernel (head_dim % 4 == 0) and the VALU tile kernel compute the same function."""
+    rng = np.random.default_rng(21)
+    B, L, H, hd, dv = 2, 150, 2, 32, 48
+    qk = dev(rng.standard_normal((B, L, 2, H, hd)).astype(np.float32))
+    v = dev(rng.standard_normal((B, L, H * dv)).astype(np.float32))
+    a = gpu_ops.softmax_attention_fwd(qk[:, :, 0], qk[:, :, 1], v).cpu().numpy()
+    monkeypatch.setenv("EGS_SOFTMAX_VALU", "1")
+    b = gpu_ops.softmax_attention_fwd(qk[:, :, 0], qk[:, :, 1], v).cpu().numpy()
+    close(a, b, rtol=1e-5)
+    want = BO.softmax_attention(qk.cpu().numpy(), v.cpu().numpy().reshape(B, L, H, dv))
+    close(a.reshape(B, L, H, dv), want, rtol=2e-5)

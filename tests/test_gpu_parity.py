@@ -601,3 +601,27 @@ def test_eig_balancing_triangular_and_diagonal(gpu_ops):
         for b in range(4):
             assert np.array_equal(np.sort(w[b].real), np.sort(np.diag(t))), (n, b)
             assert np.all(w[b].imag == 0.0)
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, L, D, d_qk, H
+    (3, 70, 24, 16, 2),        # head_dim 8 (MFMA J = 4, zero-padded)
+    (2, 200, 32, 48, 2),       # head_dim 24
+    (2, 129, 40, 128, 1),      # head_dim 128, ragged last tile
+    (1, 90, 16, 20, 2),        # head_dim 10: not a multiple of 4 -> VALU tile kernel
+])
+def test_softmax_eta_matrix_core_and_valu_kernels(gpu_ops, monkeypatch, cfg):
+    """K4: the matrix-core row-statistics kernel and the VALU tile kernel against the oracle and each other."""
+    B, L, D, d_qk, H = cfg
+    rng = np.random.default_rng(sum(cfg))
+    x = rng.standard_normal((B, L, D)).astype(np.float32)
+    w = (rng.standard_normal((2 * d_qk + D, D)) / np.sqrt(D)).astype(np.float32)
+    b = (rng.standard_normal(2 * d_qk + D) * 0.1).astype(np.float32)
+    want = O.eta_softmax(x, w, b, d_qk, H, D)[..., 0]
+    got = gpu_ops.softmax_eta(dev(x), dev(w[: 2 * d_qk]), dev(b[: 2 * d_qk]), d_qk, H).cpu().numpy()
+    monkeypatch.setenv("EGS_SOFTMAX_VALU", "1")
+    valu = gpu_ops.softmax_eta(dev(x), dev(w[: 2 * d_qk]), dev(b[: 2 * d_qk]), d_qk, H).cpu().numpy()
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-5 * scale
+    assert np.abs(valu - want).max() <= 2e-5 * scale
+    assert np.abs(got - valu).max() <= 2e-6 * scale
