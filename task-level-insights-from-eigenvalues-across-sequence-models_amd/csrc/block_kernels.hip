@@ -30,6 +30,7 @@
 namespace egs {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRecT = 4;          // tokens per block (prefetch / LDS exchange granularity)
 constexpr int kRecPad = 8;        // record streams are zero-padded to a multiple of this many tokens
@@ -338,6 +339,251 @@ __global__ __launch_bounds__(RS * 64) void linrec_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Chunked evaluation of the UN-GATED recurrence (decay = 1: linear / normalised attention) on the matrix cores
+// (v_mfma_f32_16x16x4_f32, exact fp32 products).  For a chunk of 16 tokens with the state S at its start,
+//     y_t = w_t ( q_t^T S  +  sum_{s<=t, s in chunk} (q_t . k_s) v_s ),        S <- S + sum_s k_s v_s^T,
+// and for linear attention  1 / w_t = q_t . ksum  +  sum_{s<=t} (q_t . k_s)  with ksum updated like a state column.
+// Every product is a 16 x 16 x 4 MFMA whose operands are ordinary per-lane values -- this is what removes the
+// operand-delivery bound of the token-by-token kernel above (there every FMA needs a fresh wave-uniform q or k).
+// Workgroup = 4 waves = one (batch row, q/k group, <= 128 channels); wave w owns channels 32 w .. 32 w + 31 (two
+// 16-wide tiles) and the state S[d][those channels] in the accumulator layout D[row 4 (l/16) + r][col l % 16], which
+// is at the same time a valid B operand (k = l / 16) for the contraction subset {16 dt + 4 g + r}:
+//   (1) P^T[s][t] = K_c Q_c^T            A = K_c (LDS [d%4][s][d/4]),  B = Q_c^T (same layout), causal mask on registers
+//   (2) Y += P V                          A = P^T register r (keys 4 g + r),  B = V[key][col]
+//   (3) Y += Q_c S                        A = Q_c[t][16 dt + 4 g + r] (one 16-byte LDS read per dt),  B = S registers
+//   (4) S += K_c^T V                      A = K_c[t = 4 kk + g][16 dt + l % 16],  B = V[t][col]
+// The column-of-ones "channel" that carries ksum is split over the waves by dt (wave w owns dt = w mod 4); the
+// partial q_t . ksum meet in LDS and are consumed one chunk later together with the delayed store of y, so a chunk costs
+// two barriers.  elu+1 and the k scale are applied while staging -- no pre-pass, no workspace.
+// ---------------------------------------------------------------------------------------------------
+template <int J>
+__global__ __launch_bounds__(256) void linattn_chunk_mfma_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, int64_t bs, int64_t ts, int64_t gs,
+    const float* __restrict__ v, int64_t v_bs, int64_t v_ts, const float* __restrict__ w_ext, float* __restrict__ y,
+    int64_t L, int channels, int groups, int cpg, int d, int phi, float kscale, int normalise) {
+    constexpr int DT = J / 4;
+    constexpr int kLdj = J + 4, kLdq = 4 * J + 4, kLdk = 4 * J + 16, kLdv = 128 + 16;
+    constexpr int XQ = (J + 15) / 16;                                 // float4 of q (and of k) per thread and chunk
+    constexpr int KSN = (DT + 3) / 4;                                 // ksum tiles owned by a wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Kj = lds;                                                  // [4][16][J + 4]
+    float* Qj = Kj + 4 * 16 * kLdj;
+    float* Qr = Qj + 4 * 16 * kLdj;                                   // [16][d + 4]
+    float* Kr = Qr + 16 * kLdq;                                       // [16][d + 16]
+    float* Vr = Kr + 16 * kLdk;                                       // [16][128 + 16]
+    float* w_in = Vr + 16 * kLdv;                                     // [2][16]
+    float* nu_part = w_in + 32;                                       // [2][4][16]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int cchunks = (cpg + 127) / 128;
+    const int grp = blockIdx.x / cchunks;
+    const int cc0 = (blockIdx.x - grp * cchunks) * 128;
+    const int cw = (cpg - cc0 < 128) ? cpg - cc0 : 128;               // live channels of this workgroup
+    const int64_t b = blockIdx.y;
+    const float* qb = q + b * bs + (int64_t)grp * gs;
+    const float* kb = k + b * bs + (int64_t)grp * gs;
+    const float* vb = v + b * v_bs + (int64_t)grp * cpg + cc0;
+    const float* wb = w_ext ? w_ext + b * L * groups + grp : nullptr;
+    float* yb = y + b * L * channels + (int64_t)grp * cpg + cc0;
+    const int st = tid >> 4, sf = tid & 15;                           // staging role: token, float4 slot
+
+    float4 qpre[XQ], kpre[XQ], vpre[2];
+    float wpre = 1.0f;
+    auto fetch = [&](int64_t t0c) {
+        const int64_t t = (t0c + st < L) ? t0c + st : L - 1;
+#pragma unroll
+        for (int x = 0; x < XQ; ++x) {
+            const int f = sf + 16 * x;
+            const int off = (4 * f < d) ? 4 * f : d - 4;
+            qpre[x] = *reinterpret_cast<const float4*>(qb + t * ts + off);
+            kpre[x] = *reinterpret_cast<const float4*>(kb + t * ts + off);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int f = sf + 16 * x;
+            const float* src = vb + t * v_ts;
+            float e[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) e[z] = src[(4 * f + z < cw) ? 4 * f + z : cw - 1];
+            vpre[x] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        if (wb != nullptr && sf == 0) wpre = wb[t * groups];
+    };
+    auto feat = [&](float x) { return phi ? (x > 0.0f ? x + 1.0f : (__expf(x) - 1.0f) + 1.0f) : x; };
+    auto stage = [&](int64_t t0c, int buf) {
+        const bool live = t0c + st < L;
+#pragma unroll
+        for (int x = 0; x < XQ; ++x) {
+            const int f = sf + 16 * x;
+            if (f < J) {
+                const bool ok = live && 4 * f < d;
+                const float qv[4] = {qpre[x].x, qpre[x].y, qpre[x].z, qpre[x].w};
+                const float kv[4] = {kpre[x].x, kpre[x].y, kpre[x].z, kpre[x].w};
+                float qo[4], ko[4];
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    qo[z] = ok ? feat(qv[z]) : 0.0f;
+                    ko[z] = ok ? feat(kv[z]) * kscale : 0.0f;
+                    Qj[(z * 16 + st) * kLdj + f] = qo[z];
+                    Kj[(z * 16 + st) * kLdj + f] = ko[z];
+                }
+                *reinterpret_cast<float4*>(Qr + st * kLdq + 4 * f) = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                *reinterpret_cast<float4*>(Kr + st * kLdk + 4 * f) = make_float4(ko[0], ko[1], ko[2], ko[3]);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int f = sf + 16 * x;
+            float4 val = vpre[x];
+            val.x = (live && 4 * f + 0 < cw) ? val.x : 0.0f;
+            val.y = (live && 4 * f + 1 < cw) ? val.y : 0.0f;
+            val.z = (live && 4 * f + 2 < cw) ? val.z : 0.0f;
+            val.w = (live && 4 * f + 3 < cw) ? val.w : 0.0f;
+            *reinterpret_cast<float4*>(Vr + st * kLdv + 4 * f) = val;
+        }
+        if (sf == 0) w_in[buf * 16 + st] = wpre;
+    };
+
+    f32x4 S[DT][2], KS[KSN];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) S[dt][0] = S[dt][1] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int x = 0; x < KSN; ++x) KS[x] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float ones_b = (c == 0) ? 1.0f : 0.0f;
+    const int col0 = 32 * wv + c;                                     // this lane's column in tile 0 (tile 1: + 16)
+
+    f32x4 Yp[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};   // outputs of the previous chunk (delayed store)
+    float nu_intra_p = 0.0f;
+    // store of chunk `t0p` (buffer `buf`): needs the partial q.ksum of all four waves, complete since the last barrier
+    auto emit = [&](int64_t t0p, int buf) {
+        float wt;
+        if (normalise) {
+            float nu = nu_intra_p;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) nu += nu_part[(buf * 4 + x) * 16 + c];
+            wt = 1.0f / nu;
+        } else {
+            wt = w_in[buf * 16 + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float wr = __shfl(wt, 4 * g + r, 64);
+            const int64_t trow = t0p + 4 * g + r;
+            if (trow < L) {
+                if (col0 < cw) yb[trow * channels + col0] = wr * Yp[0][r];
+                if (col0 + 16 < cw) yb[trow * channels + col0 + 16] = wr * Yp[1][r];
+            }
+        }
+    };
+
+    fetch(0);
+    int buf = 0;
+    for (int64_t t0 = 0; t0 < L; t0 += 16, buf ^= 1) {
+        __syncthreads();                                              // previous chunk: LDS reads and nu_part writes done
+        stage(t0, buf);
+        __syncthreads();
+        fetch(t0 + 16 < L ? t0 + 16 : 0);
+        if (t0 > 0) emit(t0 - 16, buf ^ 1);
+
+        // (1) transposed causal score tile
+        f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pb = {0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            const float* kr = Kj + (g * 16 + c) * kLdj;
+            const float* qr = Qj + (g * 16 + c) * kLdj;
+#pragma unroll
+            for (int jj = 0; jj < J; jj += 4) {
+                const float4 k4 = *reinterpret_cast<const float4*>(kr + jj);
+                const float4 q4 = *reinterpret_cast<const float4*>(qr + jj);
+                pa = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.x, q4.x, pa, 0, 0, 0);
+                pb = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.y, q4.y, pb, 0, 0, 0);
+                pa = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.z, q4.z, pa, 0, 0, 0);
+                pb = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.w, q4.w, pb, 0, 0, 0);
+            }
+        }
+        float P[4];
+        float nu_intra = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            P[r] = (4 * g + r <= c) ? pa[r] + pb[r] : 0.0f;           // key s = 4 g + r, query t = c
+            nu_intra += P[r];
+        }
+        nu_intra += __shfl_xor(nu_intra, 16, 64);
+        nu_intra += __shfl_xor(nu_intra, 32, 64);
+
+        // V operands of this lane: keys 4 kk + g (the same rows serve (2) with kk = r and (4))
+        float vB[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            vB[kk][0] = Vr[(4 * kk + g) * kLdv + col0];
+            vB[kk][1] = Vr[(4 * kk + g) * kLdv + col0 + 16];
+        }
+        f32x4 Y[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+        f32x4 NU = {0.0f, 0.0f, 0.0f, 0.0f};
+        // (2) intra-chunk: P register r holds keys 4 g + r; its V rows are Vr[4 g + r] -- NOT the vB rows (4 kk + g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v0 = Vr[(4 * g + r) * kLdv + col0];
+            const float v1 = Vr[(4 * g + r) * kLdv + col0 + 16];
+            Y[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], v0, Y[0], 0, 0, 0);
+            Y[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], v1, Y[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            // (3) inter-chunk: A = q_t[16 dt + 4 g + r], B = S[dt] register r
+            const float4 q4 = *reinterpret_cast<const float4*>(Qr + c * kLdq + 16 * dt + 4 * g);
+            const float qa[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Y[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[r], S[dt][0][r], Y[0], 0, 0, 0);
+                Y[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[r], S[dt][1][r], Y[1], 0, 0, 0);
+            }
+            if ((dt & 3) == wv) {                                     // wave-uniform: this wave's slice of q . ksum
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    NU = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[r], KS[dt >> 2][r], NU, 0, 0, 0);
+            }
+            // (4) state update: A = k_t[16 dt + c] for t = 4 kk + g, B = v_t
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float a = Kr[(4 * kk + g) * kLdk + 16 * dt + c];
+                S[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vB[kk][0], S[dt][0], 0, 0, 0);
+                S[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vB[kk][1], S[dt][1], 0, 0, 0);
+                if ((dt & 3) == wv) KS[dt >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ones_b, KS[dt >> 2], 0, 0, 0);
+            }
+        }
+        if (c == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nu_part[(buf * 4 + wv) * 16 + 4 * g + r] = NU[r];
+        }
+        Yp[0] = Y[0];
+        Yp[1] = Y[1];
+        nu_intra_p = nu_intra;
+    }
+    __syncthreads();
+    {
+        const int64_t nchunks = (L + 15) / 16;
+        emit((nchunks - 1) * 16, (int)((nchunks - 1) & 1));
+    }
+}
+
+template <int J>
+static int linattn_chunk_mfma_launch(const float* q, const float* k, int64_t bs, int64_t ts, int64_t gs, const float* v,
+                                     int64_t v_bs, int64_t v_ts, const float* w, float* y, int64_t batch, int64_t L,
+                                     int channels, int groups, int cpg, int d, int phi, float kscale, int normalise,
+                                     hipStream_t stream) {
+    const size_t dyn = ((size_t)2 * 4 * 16 * (J + 4) + 16 * (4 * J + 4) + 16 * (4 * J + 16) + 16 * (128 + 16) + 32 + 128) *
+                       sizeof(float);
+    if (dyn > 48 * 1024)
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_chunk_mfma_kernel<J>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    const dim3 grid((unsigned)(((cpg + 127) / 128) * groups), (unsigned)batch);
+    hipLaunchKernelGGL(linattn_chunk_mfma_kernel<J>, grid, dim3(256), dyn, stream, q, k, bs, ts, gs, v, v_bs, v_ts, w, y, L,
+                       channels, groups, cpg, d, phi, kscale, normalise);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
 // Register tiling: CT column tiles per wave (2 when the group has an even number of 64-column tiles: every scalar
 // q/k operand then feeds two FMAs), RS waves per workgroup splitting d_state (DR = rows per wave in {16, 32, 64}).
 // RS grows until the launch has >= 4 waves per SIMD to hide the scalar-load latency, or DR reaches 16.
@@ -408,6 +654,20 @@ int linrec_launch(const float* q, const float* k, int64_t qk_bs, int64_t qk_ts, 
     if (groups * 8 > 65535) {
         set_error("too many q/k groups: %d", groups);
         return -18;
+    }
+    // un-gated form on the matrix cores (no skip term, d_state <= 128, 16-byte aligned q / k rows)
+    if (decay == nullptr && skip == nullptr && d_state % 4 == 0 && d_state <= 128 && qk_bs % 4 == 0 && qk_ts % 4 == 0 &&
+        qk_gs % 4 == 0 && reinterpret_cast<uintptr_t>(q) % 16 == 0 && reinterpret_cast<uintptr_t>(k) % 16 == 0 &&
+        !getenv("EGS_REC_VALU")) {
+#define EGS_CHUNK_ARGS                                                                                                  \
+    q, k, qk_bs, qk_ts, qk_gs, v, v_bs, v_ts, normalise ? nullptr : w, y, batch, seqlen, channels, groups, cols_per_group, \
+        d_state, phi, k_scale, normalise, stream
+        const int j4 = d_state / 4;
+        if (j4 <= 4) return linattn_chunk_mfma_launch<4>(EGS_CHUNK_ARGS);
+        if (j4 <= 8) return linattn_chunk_mfma_launch<8>(EGS_CHUNK_ARGS);
+        if (j4 <= 16) return linattn_chunk_mfma_launch<16>(EGS_CHUNK_ARGS);
+        return linattn_chunk_mfma_launch<32>(EGS_CHUNK_ARGS);
+#undef EGS_CHUNK_ARGS
     }
     const RecTiling tl = linrec_tiling(batch, channels, cols_per_group, d_state);
     const size_t need_ws = linrec_workspace_bytes(batch, seqlen, channels, cols_per_group, d_state);
@@ -661,8 +921,6 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_kernel(const float* __re
 // The output accumulators are in the D layout (row 4 (l/16) + r, column l % 16); the per-row rescale factors reach
 // them with 4 lane shuffles per block.
 // ---------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 template <int J, int NT>
 __global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t qk_bs, int64_t qk_ts, int64_t qk_hs,

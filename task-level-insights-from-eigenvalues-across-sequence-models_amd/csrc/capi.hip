@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "egs_common.h"
 
 namespace egs {
@@ -241,10 +243,13 @@ int egs_threshold_hist(const void* vals, int dtype, int transform, int64_t outer
                                  as_stream(stream));
 }
 
-size_t egs_linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int d_state) {
+size_t egs_linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int d_state,
+                                  int gated_or_skip, int qk_aligned) {
     if (batch <= 0 || seqlen <= 0 || channels <= 0 || cols_per_group <= 0 || d_state <= 0 ||
         channels % cols_per_group != 0)
         return 512;
+    if (!gated_or_skip && qk_aligned && d_state % 4 == 0 && d_state <= 128 && !getenv("EGS_REC_VALU"))
+        return 512;                                                   // matrix-core path: no scratch
     return linrec_workspace_bytes(batch, seqlen, channels, cols_per_group, d_state);
 }
 

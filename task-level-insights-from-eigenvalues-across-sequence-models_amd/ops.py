@@ -287,7 +287,9 @@ def linear_recurrence_fwd(q, k, v, decay=None, vscale=None, w=None, skip=None, p
     y = torch.empty((batch, seqlen, channels), dtype=torch.float32, device=v.device)
     if batch == 0 or seqlen == 0:
         return y
-    need = lib().egs_linrec_workspace_bytes(batch, seqlen, channels, cpg, d_state)
+    aligned = (q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0 and all(st % 4 == 0 for st in q.stride()[:3]))
+    need = lib().egs_linrec_workspace_bytes(batch, seqlen, channels, cpg, d_state,
+                                            1 if (decay is not None or skip is not None) else 0, 1 if aligned else 0)
     ws = _workspace(v.device, need)
     with torch.cuda.device(v.device):
         check(lib().egs_linear_recurrence_fwd(

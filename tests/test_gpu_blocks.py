@@ -255,3 +255,45 @@ def test_softmax_attention_mfma_and_valu_paths_agree(gpu_ops, monkeypatch):
     close(a, b, rtol=1e-5)
     want = BO.softmax_attention(qk.cpu().numpy(), v.cpu().numpy().reshape(B, L, H, dv))
     close(a.reshape(B, L, H, dv), want, rtol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [
+    # B, L, G, d, cols_per_group
+    (2, 16, 1, 16, 64),        # exactly one chunk
+    (3, 37, 2, 8, 12),         # ragged chunk, narrow tiles (one live wave), two groups
+    (1, 100, 1, 128, 128),     # d = 128, all four waves, several chunks
+    (2, 65, 1, 64, 200),       # two channel chunks per group (128 + 72)
+    (5, 1, 3, 4, 5),           # single token
+    (2, 50, 1, 20, 40),        # d % 16 != 0 (zero-padded state rows)
+])
+@pytest.mark.parametrize("mode", ["normalise", "w", "plain"])
+def test_linear_recurrence_chunked_matrix_core_path(gpu_ops, monkeypatch, shape, mode):
+    """The un-gated form runs chunk-wise on the matrix cores; it must agree with the oracle and with the token-by-token
+    kernel (forced through EGS_REC_VALU)."""
+    B, L, G, d, cpg = shape
+    C = G * cpg
+    rng = np.random.default_rng(sum(shape))
+    q = rng.standard_normal((B, L, G, d)).astype(np.float32)
+    k = rng.standard_normal((B, L, G, d)).astype(np.float32)
+    v = rng.standard_normal((B, L, C)).astype(np.float32)
+    phi = mode != "plain"
+    kw = {}
+    if mode == "w":
+        kw["w"] = dev(rng.uniform(0.5, 2.0, (B, L, G)).astype(np.float32))
+        kw["k_scale"] = 0.37
+    if mode == "plain":
+        q, k = (q / np.sqrt(d)).astype(np.float32), (k / np.sqrt(d)).astype(np.float32)
+    args = (dev(q), dev(k), dev(v))
+    got = gpu_ops.linear_recurrence_fwd(*args, phi=phi, normalise=(mode == "normalise"), **kw).cpu().numpy()
+    qf, kf = (BO.elu1(q), BO.elu1(k)) if phi else (q, k)
+    if mode == "normalise":
+        wn = np.float32(1) / np.einsum("blgd,blgd->blg", qf, np.cumsum(kf, axis=1, dtype=np.float32)).astype(np.float32)
+    elif mode == "w":
+        wn, kf = kw["w"].cpu().numpy(), kf * np.float32(0.37)
+    else:
+        wn = None
+    want = BO.linear_recurrence(qf, kf, v, w=wn)
+    close(got, want, rtol=3e-5)
+    monkeypatch.setenv("EGS_REC_VALU", "1")
+    valu = gpu_ops.linear_recurrence_fwd(*args, phi=phi, normalise=(mode == "normalise"), **kw).cpu().numpy()
+    close(got, valu, rtol=3e-5)
