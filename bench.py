@@ -275,6 +275,31 @@ def stream_rooflines(ops, device):
                 "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "ms": ms,
                 "note": "fp32 MFMA (= fp32 vector peak); whole op incl. the fp64 scan",
                 "hbm_gbs_algorithmic": B * L * (4 * D + 8) / ms / 1e6})
+    del x
+    # K4: softmax eta on the 4096-sequence MQAR batch (L = 512, hidden 128, d_qk = 64): two passes of causal score tiles
+    B, L, D, dqk = 4096, 512, 128, 64
+    x = torch.randn((B, L, D), generator=g, device=device)
+    w = (torch.rand((2 * dqk, D), generator=g, device=device) * 2 - 1) / np.sqrt(D)
+    b = (torch.rand((2 * dqk,), generator=g, device=device) * 2 - 1) / np.sqrt(D)
+    ms = med(lambda: ops.softmax_eta(x, w, b, dqk, 1), reps=3)
+    tf = (2 * B * L * (L + 1) / 2 * dqk * 2 + B * L * 2.0 * D * 2 * dqk) / ms / 1e9
+    out.append({"kernel": "qk_proj_mfma_kernel + softmax_nu_mfma_kernel + eta_finalize",
+                "workload": "MQAR analysis batch: softmax attention eta, B=4096, L=512, D=128, d_qk=64, H=1",
+                "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "ms": ms,
+                "note": "fp32 MFMA; algorithmic flops = projection + 2 passes of the causal q.k tiles; the fp64 "
+                        "exp / sum of pass 2 runs on the vector pipe beside it"})
+    del x
+    # block forward: causal linear attention mixer on one GPU's shard of C4
+    B, L, D, dqk = 512, 4096, 128, 128
+    qk = torch.randn((B, L, 2, 1, dqk), generator=g, device=device) / np.sqrt(dqk)
+    v = torch.randn((B, L, D), generator=g, device=device)
+    ms = med(lambda: ops.linear_recurrence_fwd(qk[:, :, 0], qk[:, :, 1], v, phi=True, normalise=True), reps=3)
+    tf = B * L * 4.0 * dqk * D / ms / 1e9
+    out.append({"kernel": "linattn_chunk_mfma_kernel",
+                "workload": "C4 / 8 GPUs block forward: causal linear attention, B=512, L=4096, d_qk=128, 128 channels",
+                "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "ms": ms,
+                "note": "fp32 MFMA, chunked recurrence; algorithmic flops = 4 d C per token (state update + readout); "
+                        "the kernel executes 1.4x that (intra-chunk tiles), matrix pipe 83 % busy (profiles/r01_blocks.json)"})
     return out
 
 

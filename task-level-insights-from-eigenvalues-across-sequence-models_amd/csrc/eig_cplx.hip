@@ -235,6 +235,7 @@ __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __res
                     }
                 }
                 fs[i] = f;
+                cn[i] = 1.0 / f;                                      // reuse: reciprocal factors (exact, powers of two)
                 if (f != 1.0) s_idx = 1;
             }
             __syncthreads();
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(kCThreads) void eig_cplx_kernel(const double* __res
             if (!any) break;
             for (int idx = tid; idx < n * n; idx += kCThreads) {
                 const int i = idx / n, j = idx - i * n;
-                HM(i, j) = zscale(HM(i, j), fs[j] / fs[i]);
+                HM(i, j) = zscale(HM(i, j), fs[j] * cn[i]);
             }
             __syncthreads();
         }

@@ -211,8 +211,9 @@ __global__ __launch_bounds__(kZH) void zhess64_kernel(const double* __restrict__
                 }
             }
             if (__ballot(f != 1.0) == 0ULL) break;
+            const double finv = 1.0 / f;                              // powers of two: exact
             for (int r = 0; r < n; ++r) {
-                const double sc = f / bcast_lane(f, r);
+                const double sc = f * bcast_lane(finv, r);
                 if (inr) ZH(r, lane) = qscale(ZH(r, lane), sc);
             }
             wave_lds_sync();

@@ -107,70 +107,123 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     // equilibrates row and column norms of the active block, which is what makes graded / badly scaled inputs accurate.
     if (balance) {
         int k0 = 0, l0 = n - 1;
-        for (int guard = 0; guard < n; ++guard) {                   // rows whose off-diagonal part in columns 0..l0 is zero
-            bool rz = false;
-            if (lane <= l0) {
-                rz = true;
-                for (int j = 0; j <= l0; ++j)
-                    if (j != lane && s[lane * kHessLd + j] != 0.0) rz = false;
-            }
-            const unsigned long long m = __ballot(rz);
-            if (m == 0ULL || l0 == 0) break;
-            const int r = uniform(63 - __builtin_clzll(m));
-            if (r != l0) {
-                if (lane <= l0) {                                   // swap columns r <-> l0 over rows 0..l0
-                    const double t = s[lane * kHessLd + r];
-                    s[lane * kHessLd + r] = s[lane * kHessLd + l0];
-                    s[lane * kHessLd + l0] = t;
+        // one batched sweep over row `lane` and column `lane` (8 loads of each in flight): off-diagonal maxima decide
+        // whether any row / column isolates an eigenvalue, the 1-norms are the first scaling pass of the common case
+        // (no permutation).  A branch per element would serialise the LDS reads (see the lesson in DESIGN.md).
+        double rmax = 0.0, cmax = 0.0, rsum = 0.0, csum = 0.0;
+        {
+            int j = 0;
+            for (; j + 8 <= n; j += 8) {
+                double xr[8], xc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    xr[u] = s[lc * kHessLd + j + u];
+                    xc[u] = s[(j + u) * kHessLd + lc];
                 }
-                wave_lds_sync();
-                if (inr) {                                          // swap rows r <-> l0 over all columns
-                    const double t = s[r * kHessLd + lane];
-                    s[r * kHessLd + lane] = s[l0 * kHessLd + lane];
-                    s[l0 * kHessLd + lane] = t;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double ar = (j + u != lane) ? fabs(xr[u]) : 0.0, ac = (j + u != lane) ? fabs(xc[u]) : 0.0;
+                    rmax = fmax(rmax, ar);
+                    cmax = fmax(cmax, ac);
+                    rsum += ar;
+                    csum += ac;
                 }
-                wave_lds_sync();
             }
-            --l0;
+            for (; j < n; ++j) {
+                const double ar = (j != lane) ? fabs(s[lc * kHessLd + j]) : 0.0;
+                const double ac = (j != lane) ? fabs(s[j * kHessLd + lc]) : 0.0;
+                rmax = fmax(rmax, ar);
+                cmax = fmax(cmax, ac);
+                rsum += ar;
+                csum += ac;
+            }
         }
-        for (int guard = 0; guard < n; ++guard) {                   // columns whose off-diagonal part in rows k0..l0 is zero
-            bool cz = false;
-            if (lane >= k0 && lane <= l0) {
-                cz = true;
-                for (int i = k0; i <= l0; ++i)
-                    if (i != lane && s[i * kHessLd + lane] != 0.0) cz = false;
-            }
-            const unsigned long long m = __ballot(cz);
-            if (m == 0ULL || k0 >= l0) break;
-            const int c = uniform(__builtin_ctzll(m));
-            if (c != k0) {
+        const bool any_iso = __ballot(inr && (rmax == 0.0 || cmax == 0.0)) != 0ULL;
+        if (any_iso && n > 1) {
+            // ---- permutation (rare path): rows, then columns, one candidate per round ----
+            for (int guard = 0; guard < n; ++guard) {               // rows whose off-diagonal part in columns 0..l0 is zero
+                bool rz = false;
                 if (lane <= l0) {
-                    const double t = s[lane * kHessLd + c];
-                    s[lane * kHessLd + c] = s[lane * kHessLd + k0];
-                    s[lane * kHessLd + k0] = t;
+                    rz = true;
+                    for (int j = 0; j <= l0; ++j)
+                        if (j != lane && s[lane * kHessLd + j] != 0.0) rz = false;
                 }
-                wave_lds_sync();
-                if (inr && lane >= k0) {
-                    const double t = s[c * kHessLd + lane];
-                    s[c * kHessLd + lane] = s[k0 * kHessLd + lane];
-                    s[k0 * kHessLd + lane] = t;
+                const unsigned long long m = __ballot(rz);
+                if (m == 0ULL || l0 == 0) break;
+                const int r = uniform(63 - __builtin_clzll(m));
+                if (r != l0) {
+                    if (lane <= l0) {                               // swap columns r <-> l0 over rows 0..l0
+                        const double t = s[lane * kHessLd + r];
+                        s[lane * kHessLd + r] = s[lane * kHessLd + l0];
+                        s[lane * kHessLd + l0] = t;
+                    }
+                    wave_lds_sync();
+                    if (inr) {                                      // swap rows r <-> l0 over all columns
+                        const double t = s[r * kHessLd + lane];
+                        s[r * kHessLd + lane] = s[l0 * kHessLd + lane];
+                        s[l0 * kHessLd + lane] = t;
+                    }
+                    wave_lds_sync();
                 }
-                wave_lds_sync();
+                --l0;
             }
-            ++k0;
+            for (int guard = 0; guard < n; ++guard) {               // columns whose off-diagonal part in rows k0..l0 is zero
+                bool cz = false;
+                if (lane >= k0 && lane <= l0) {
+                    cz = true;
+                    for (int i = k0; i <= l0; ++i)
+                        if (i != lane && s[i * kHessLd + lane] != 0.0) cz = false;
+                }
+                const unsigned long long m = __ballot(cz);
+                if (m == 0ULL || k0 >= l0) break;
+                const int c = uniform(__builtin_ctzll(m));
+                if (c != k0) {
+                    if (lane <= l0) {
+                        const double t = s[lane * kHessLd + c];
+                        s[lane * kHessLd + c] = s[lane * kHessLd + k0];
+                        s[lane * kHessLd + k0] = t;
+                    }
+                    wave_lds_sync();
+                    if (inr && lane >= k0) {
+                        const double t = s[c * kHessLd + lane];
+                        s[c * kHessLd + lane] = s[k0 * kHessLd + lane];
+                        s[k0 * kHessLd + lane] = t;
+                    }
+                    wave_lds_sync();
+                }
+                ++k0;
+            }
         }
         // scaling of the block [k0, l0]: all factors of a pass are computed from the same matrix (Jacobi form of the
         // Parlett-Reinsch iteration; powers of two, so the similarity is exact in floating point)
+        const bool win = lane >= k0 && lane <= l0;
         for (int pass = 0; pass < 16; ++pass) {
-            double f = 1.0;
-            if (lane >= k0 && lane <= l0) {
-                double c = 0.0, r = 0.0;
-                for (int j = k0; j <= l0; ++j) {
-                    if (j != lane) {
-                        c += fabs(s[j * kHessLd + lane]);
-                        r += fabs(s[lane * kHessLd + j]);
+            if (pass > 0 || any_iso) {                              // norms over the window, 8 loads of each in flight
+                rsum = 0.0;
+                csum = 0.0;
+                int j = k0;
+                for (; j + 8 <= l0 + 1; j += 8) {
+                    double xr[8], xc[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        xr[u] = s[lc * kHessLd + j + u];
+                        xc[u] = s[(j + u) * kHessLd + lc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        rsum += (j + u != lane) ? fabs(xr[u]) : 0.0;
+                        csum += (j + u != lane) ? fabs(xc[u]) : 0.0;
                     }
                 }
+                for (; j <= l0; ++j) {
+                    rsum += (j != lane) ? fabs(s[lc * kHessLd + j]) : 0.0;
+                    csum += (j != lane) ? fabs(s[j * kHessLd + lc]) : 0.0;
+                }
+            }
+            double f = 1.0;
+            if (win) {
+                double c = csum;
+                const double r = rsum;
                 if (c != 0.0 && r != 0.0 && c < 1e300 && r < 1e300) {
                     const double s0 = c + r;
                     double g = r * 0.5;
@@ -187,10 +240,24 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
                 }
             }
             if (__ballot(f != 1.0) == 0ULL) break;
-            // A(r, c) <- A(r, c) * f_c / f_r   (lane = column c; f_r broadcast from lane r)
-            for (int r = 0; r < n; ++r) {
-                const double fr = bcast_lane(f, r);
-                if (inr) s[r * kHessLd + lane] = s[r * kHessLd + lane] * f / fr;
+            // A(r, c) <- A(r, c) * f_c / f_r   (lane = column c; 1 / f_r, exact for a power of two, broadcast from lane r)
+            const double finv = 1.0 / f;
+            {
+                int r = 0;
+                for (; r + 8 <= n; r += 8) {
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = s[(r + u) * kHessLd + lc];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double fri = bcast_lane(finv, r + u);
+                        if (inr) s[(r + u) * kHessLd + lane] = (x[u] * f) * fri;
+                    }
+                }
+                for (; r < n; ++r) {
+                    const double fri = bcast_lane(finv, r);
+                    if (inr) s[r * kHessLd + lane] = (s[r * kHessLd + lc] * f) * fri;
+                }
             }
             wave_lds_sync();
         }
