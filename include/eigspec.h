@@ -179,12 +179,20 @@ int egs_threshold_hist(const void* vals, int dtype, int transform, int64_t outer
  *   w      : [B, L, G] contiguous or NULL (= 1); ignored when normalise != 0
  *   skip   : [channels] or NULL (= 0)
  *   y      : [B, L, channels] contiguous
- * d_state <= 512.  Two kernels serve it: the un-gated form (decay == NULL, skip == NULL) with d_state % 4 == 0,
- * d_state <= 128 and 16-byte aligned q / k rows (pointer and strides) runs chunk-wise on the matrix cores and needs no
- * workspace; everything else runs token by token and needs egs_linrec_workspace_bytes (compact transformed q, k and
- * the normaliser).  `gated_or_skip` / `qk_aligned` tell the query which of the two the call will take. */
-size_t egs_linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int d_state,
-                                  int gated_or_skip, int qk_aligned);
+ * d_state <= 512.  Three kernels serve it.  With d_state % 4 == 0, d_state <= 128 and 16-byte aligned q / k rows
+ * (pointer and strides) the recurrence runs chunk-wise on the matrix cores and needs NO workspace: the un-gated form
+ * (decay == NULL, skip == NULL), and the gated form without w / phi / normalise / k_scale when cols_per_group and
+ * cols_per_decay are multiples of 32.  Everything else runs token by token and needs the workspace (compact transformed
+ * q, k and the normaliser).  `flags` describes the call to the query with the EGS_REC_* bits below. */
+#define EGS_REC_GATED 1      /* decay / vscale given */
+#define EGS_REC_W 2          /* w given (and normalise == 0) */
+#define EGS_REC_SKIP 4       /* skip given */
+#define EGS_REC_PHI 8        /* phi != 0 */
+#define EGS_REC_NORMALISE 16 /* normalise != 0 */
+#define EGS_REC_KSCALE 32    /* k_scale != 1 */
+#define EGS_REC_ALIGNED 64   /* q, k pointers 16-byte aligned and their strides multiples of 4 elements */
+size_t egs_linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int cols_per_decay,
+                                  int d_state, unsigned flags);
 int egs_linear_recurrence_fwd(const float* q, const float* k, int64_t qk_batch_stride, int64_t qk_token_stride,
                               int64_t qk_group_stride, const float* v, int64_t v_batch_stride,
                               int64_t v_token_stride, const float* decay, const float* vscale, const float* w,

@@ -46,7 +46,7 @@ SIGNATURES = {
     "egs_threshold_hist": (_i, [_vp, _i, _i, _i64, _i64, _i64, _c.POINTER(_c.c_double), _i, _vp, _vp]),
     "egs_softmax_attention_fwd": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i,
                                        _c.c_float, _vp]),
-    "egs_linrec_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i, _i]),
+    "egs_linrec_workspace_bytes": (_sz, [_i64, _i64, _i, _i, _i, _i, _c.c_uint]),
     "egs_linear_recurrence_fwd": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
                                        _i, _i, _i, _i, _i, _c.c_float, _i, _vp, _sz, _vp]),
 }

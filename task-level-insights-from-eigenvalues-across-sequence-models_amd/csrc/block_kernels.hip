@@ -567,6 +567,253 @@ __global__ __launch_bounds__(256) void linattn_chunk_mfma_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The GATED recurrence (Mamba-2 SSD) chunk-wise on the matrix cores.  With l_t = sum_{u<=t} log a_u inside a chunk
+// (a = per-head decay),
+//     y_t = e^{l_t} q_t^T S_0 + sum_{s<=t} e^{l_t - l_s} (q_t . k_s) (dt_s v_s) + D v_t,
+//     S   = e^{l_T} S_0 + sum_s e^{l_T - l_s} k_s (dt_s v_s)^T,
+// i.e. the same four MFMA products as the un-gated kernel with the decay factors applied on registers: on the score
+// tile (1), on the rows of the inter-chunk product (3), on the A operand and the accumulators of the state update (4).
+// All exponents are <= 0, so nothing overflows; a decay of exactly 0 is floored at e^-87 (its products underflow to 0
+// in fp32 like the reference's).  One wave = 32 channels must lie inside one head (cols_per_decay % 32 == 0).
+// ---------------------------------------------------------------------------------------------------
+template <int J>
+__global__ __launch_bounds__(256) void ssd_chunk_mfma_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, int64_t bs, int64_t ts, int64_t gs,
+    const float* __restrict__ v, int64_t v_bs, int64_t v_ts, const float* __restrict__ decay,
+    const float* __restrict__ vscale, const float* __restrict__ skip, float* __restrict__ y, int64_t L, int channels,
+    int groups, int cpg, int cpd, int d) {
+    constexpr int DT = J / 4;
+    constexpr int kLdj = J + 4, kLdq = 4 * J + 4, kLdk = 4 * J + 16, kLdv = 128 + 16;
+    constexpr int XQ = (J + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Kj = lds;                                                  // [4][16][J + 4]
+    float* Qj = Kj + 4 * 16 * kLdj;
+    float* Qr = Qj + 4 * 16 * kLdj;                                   // [16][d + 4]
+    float* Kr = Qr + 16 * kLdq;                                       // [16][d + 16]
+    float* Vs = Kr + 16 * kLdk;                                       // [16][128 + 16]   dt_t * v_t
+    float* Vraw = Vs + 16 * kLdv;                                     // [16][128 + 16]   v_t (skip term)
+    float* cum = Vraw + 16 * kLdv;                                    // [4 waves][16]    l_t of the wave's head
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int cchunks = (cpg + 127) / 128;
+    const int grp = blockIdx.x / cchunks;
+    const int cc0 = (blockIdx.x - grp * cchunks) * 128;
+    const int cw = (cpg - cc0 < 128) ? cpg - cc0 : 128;
+    const int64_t b = blockIdx.y;
+    const int nh = channels / cpd;
+    const float* qb = q + b * bs + (int64_t)grp * gs;
+    const float* kb = k + b * bs + (int64_t)grp * gs;
+    const float* vb = v + b * v_bs + (int64_t)grp * cpg + cc0;
+    float* yb = y + b * L * channels + (int64_t)grp * cpg + cc0;
+    const int st = tid >> 4, sf = tid & 15;                           // staging role: token, float4 slot
+    const int ch0 = grp * cpg + cc0;                                  // first channel of this workgroup
+
+    // operands of a chunk, fetched TWO chunks ahead (the per-chunk work is short for small d_state, so one chunk of
+    // compute does not cover the HBM latency)
+    struct Pre {
+        float4 q[XQ], k[XQ], v[2];
+        float s[2], l;
+    };
+    Pre preA, preB;
+    auto fetch = [&](Pre& pr, int64_t t0c) {
+        float4(&qpre)[XQ] = pr.q;
+        float4(&kpre)[XQ] = pr.k;
+        float4(&vpre)[2] = pr.v;
+        float(&spre)[2] = pr.s;
+        float& lpre = pr.l;
+        const int64_t t = (t0c + st < L) ? t0c + st : L - 1;
+#pragma unroll
+        for (int x = 0; x < XQ; ++x) {
+            const int f = sf + 16 * x;
+            const int off = (4 * f < d) ? 4 * f : d - 4;
+            qpre[x] = *reinterpret_cast<const float4*>(qb + t * ts + off);
+            kpre[x] = *reinterpret_cast<const float4*>(kb + t * ts + off);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int f = sf + 16 * x;
+            const float* src = vb + t * v_ts;
+            float e[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) e[z] = src[(4 * f + z < cw) ? 4 * f + z : cw - 1];
+            vpre[x] = make_float4(e[0], e[1], e[2], e[3]);
+            const int chn = ch0 + ((4 * f < cw) ? 4 * f : cw - 1);    // the 4 channels of a float4 share a head (cpd % 32 == 0)
+            spre[x] = vscale[(b * L + t) * nh + chn / cpd];
+        }
+        if (sf < 4) {                                                 // log-decay of wave sf's head for token st
+            const int chn = ch0 + ((32 * sf < cw) ? 32 * sf : cw - 1);
+            lpre = __log2f(fmaxf(decay[(b * L + t) * nh + chn / cpd], 1.6e-38f));   // base 2: the factors are one v_exp_f32
+        }
+    };
+    auto stage = [&](const Pre& pr, int64_t t0c) {
+        const float4(&qpre)[XQ] = pr.q;
+        const float4(&kpre)[XQ] = pr.k;
+        const float4(&vpre)[2] = pr.v;
+        const float(&spre)[2] = pr.s;
+        const float lpre = pr.l;
+        const bool live = t0c + st < L;
+#pragma unroll
+        for (int x = 0; x < XQ; ++x) {
+            const int f = sf + 16 * x;
+            if (f < J) {
+                const bool ok = live && 4 * f < d;
+                const float qv[4] = {qpre[x].x, qpre[x].y, qpre[x].z, qpre[x].w};
+                const float kv[4] = {kpre[x].x, kpre[x].y, kpre[x].z, kpre[x].w};
+                float qo[4], ko[4];
+#pragma unroll
+                for (int z = 0; z < 4; ++z) {
+                    qo[z] = ok ? qv[z] : 0.0f;
+                    ko[z] = ok ? kv[z] : 0.0f;
+                    Qj[(z * 16 + st) * kLdj + f] = qo[z];
+                    Kj[(z * 16 + st) * kLdj + f] = ko[z];
+                }
+                *reinterpret_cast<float4*>(Qr + st * kLdq + 4 * f) = make_float4(qo[0], qo[1], qo[2], qo[3]);
+                *reinterpret_cast<float4*>(Kr + st * kLdk + 4 * f) = make_float4(ko[0], ko[1], ko[2], ko[3]);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int f = sf + 16 * x;
+            float4 val = vpre[x];
+            val.x = (live && 4 * f + 0 < cw) ? val.x : 0.0f;
+            val.y = (live && 4 * f + 1 < cw) ? val.y : 0.0f;
+            val.z = (live && 4 * f + 2 < cw) ? val.z : 0.0f;
+            val.w = (live && 4 * f + 3 < cw) ? val.w : 0.0f;
+            *reinterpret_cast<float4*>(Vraw + st * kLdv + 4 * f) = val;
+            const float sc = spre[x];
+            *reinterpret_cast<float4*>(Vs + st * kLdv + 4 * f) = make_float4(val.x * sc, val.y * sc, val.z * sc, val.w * sc);
+        }
+        if (sf < 4) cum[sf * 16 + st] = live ? lpre : 0.0f;           // per-token log decay; prefix-summed after the barrier
+    };
+
+    f32x4 S[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) S[dt][0] = S[dt][1] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int col0 = 32 * wv + c;
+    const float sk0 = (skip != nullptr && col0 < cw) ? skip[ch0 + col0] : 0.0f;
+    const float sk1 = (skip != nullptr && col0 + 16 < cw) ? skip[ch0 + col0 + 16] : 0.0f;
+
+    auto chunk = [&](Pre& pr, int64_t t0) {
+        __syncthreads();                                              // previous chunk's LDS reads are done
+        stage(pr, t0);
+        __syncthreads();
+        fetch(pr, t0 + 32 < L ? t0 + 32 : 0);
+        // l_t = inclusive prefix sum (base-2 logs) of this wave's head: a 16-lane DPP scan by lanes 0..15, parked in
+        // the wave's own LDS row, from which every lane picks the nine values it needs
+        {
+            float x = cum[wv * 16 + c];
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, false));
+            wave_lds_sync();                                          // every lane has read the raw values
+            if (g == 0) cum[wv * 16 + c] = x;
+            wave_lds_sync();
+        }
+        const float l_end = cum[wv * 16 + 15];
+        const float l_c = cum[wv * 16 + c];                           // l_t for this lane's query token t = c
+        float l_row[4], l_kk[4];                                      // l for tokens 4 g + r  /  4 kk + g
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            l_row[r] = cum[wv * 16 + 4 * g + r];
+            l_kk[r] = cum[wv * 16 + 4 * r + g];
+        }
+
+        // (1) transposed causal score tile with the decay e^{l_t - l_s}
+        f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pb = {0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            const float* kr = Kj + (g * 16 + c) * kLdj;
+            const float* qr = Qj + (g * 16 + c) * kLdj;
+#pragma unroll
+            for (int jj = 0; jj < J; jj += 4) {
+                const float4 k4 = *reinterpret_cast<const float4*>(kr + jj);
+                const float4 q4 = *reinterpret_cast<const float4*>(qr + jj);
+                pa = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.x, q4.x, pa, 0, 0, 0);
+                pb = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.y, q4.y, pb, 0, 0, 0);
+                pa = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.z, q4.z, pa, 0, 0, 0);
+                pb = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.w, q4.w, pb, 0, 0, 0);
+            }
+        }
+        float P[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)                                   // key s = 4 g + r, query t = c
+            P[r] = (4 * g + r <= c) ? (pa[r] + pb[r]) * __builtin_amdgcn_exp2f(l_c - l_row[r]) : 0.0f;
+
+        float vB[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            vB[kk][0] = Vs[(4 * kk + g) * kLdv + col0];
+            vB[kk][1] = Vs[(4 * kk + g) * kLdv + col0 + 16];
+        }
+        f32x4 Y[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};    // intra-chunk part
+        f32x4 Yi[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};   // q_t^T S_0, scaled by e^{l_t} afterwards
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v0 = Vs[(4 * g + r) * kLdv + col0];
+            const float v1 = Vs[(4 * g + r) * kLdv + col0 + 16];
+            Y[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], v0, Y[0], 0, 0, 0);
+            Y[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], v1, Y[1], 0, 0, 0);
+        }
+        const float e_end = __builtin_amdgcn_exp2f(l_end);
+        float ek[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ek[kk] = __builtin_amdgcn_exp2f(l_end - l_kk[kk]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float4 q4 = *reinterpret_cast<const float4*>(Qr + c * kLdq + 16 * dt + 4 * g);
+            const float qa[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Yi[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[r], S[dt][0][r], Yi[0], 0, 0, 0);
+                Yi[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[r], S[dt][1][r], Yi[1], 0, 0, 0);
+            }
+            S[dt][0] *= e_end;
+            S[dt][1] *= e_end;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float a = Kr[(4 * kk + g) * kLdk + 16 * dt + c] * ek[kk];
+                S[dt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vB[kk][0], S[dt][0], 0, 0, 0);
+                S[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vB[kk][1], S[dt][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t trow = t0 + 4 * g + r;
+            if (trow < L) {
+                const float er = __builtin_amdgcn_exp2f(l_row[r]);
+                if (col0 < cw)
+                    yb[trow * channels + col0] = fmaf(er, Yi[0][r], Y[0][r]) + sk0 * Vraw[(4 * g + r) * kLdv + col0];
+                if (col0 + 16 < cw)
+                    yb[trow * channels + col0 + 16] =
+                        fmaf(er, Yi[1][r], Y[1][r]) + sk1 * Vraw[(4 * g + r) * kLdv + col0 + 16];
+            }
+        }
+    };
+    fetch(preA, 0);
+    fetch(preB, 16 < L ? 16 : 0);
+    for (int64_t t0 = 0; t0 < L; t0 += 32) {
+        chunk(preA, t0);
+        if (t0 + 16 < L) chunk(preB, t0 + 16);
+    }
+}
+template <int J>
+static int ssd_chunk_mfma_launch(const float* q, const float* k, int64_t bs, int64_t ts, int64_t gs, const float* v,
+                                 int64_t v_bs, int64_t v_ts, const float* decay, const float* vscale, const float* skip,
+                                 float* y, int64_t batch, int64_t L, int channels, int groups, int cpg, int cpd, int d,
+                                 hipStream_t stream) {
+    const size_t dyn = ((size_t)2 * 4 * 16 * (J + 4) + 16 * (4 * J + 4) + 16 * (4 * J + 16) + 2 * 16 * (128 + 16) + 64) *
+                       sizeof(float);
+    if (dyn > 48 * 1024)
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ssd_chunk_mfma_kernel<J>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    const dim3 grid((unsigned)(((cpg + 127) / 128) * groups), (unsigned)batch);
+    hipLaunchKernelGGL(ssd_chunk_mfma_kernel<J>, grid, dim3(256), dyn, stream, q, k, bs, ts, gs, v, v_bs, v_ts, decay, vscale,
+                       skip, y, L, channels, groups, cpg, cpd, d);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int J>
 static int linattn_chunk_mfma_launch(const float* q, const float* k, int64_t bs, int64_t ts, int64_t gs, const float* v,
                                      int64_t v_bs, int64_t v_ts, const float* w, float* y, int64_t batch, int64_t L,
@@ -615,6 +862,16 @@ static RecTiling linrec_tiling(int64_t batch, int channels, int cols_per_group, 
     return t;
 }
 
+// Which kernel serves a call (one definition for the workspace query and the launcher): 1 = un-gated chunked MFMA,
+// 2 = gated (SSD) chunked MFMA, 0 = token-by-token kernel (needs the workspace).
+enum { kRecGated = 1, kRecW = 2, kRecSkip = 4, kRecPhi = 8, kRecNormalise = 16, kRecKScale = 32, kRecAligned = 64 };
+int linrec_path(int d_state, int cols_per_group, int cols_per_decay, unsigned flags) {
+    if (!(flags & kRecAligned) || d_state % 4 != 0 || d_state > 128 || getenv("EGS_REC_VALU")) return 0;
+    if (!(flags & kRecGated)) return (flags & kRecSkip) ? 0 : 1;
+    if (flags & (kRecW | kRecPhi | kRecNormalise | kRecKScale)) return 0;
+    return (cols_per_decay % 32 == 0 && cols_per_group % 32 == 0) ? 2 : 0;
+}
+
 size_t linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int d_state) {
     const RecTiling t = linrec_tiling(batch, channels, cols_per_group, d_state);
     const int64_t groups = channels / cols_per_group;
@@ -655,10 +912,14 @@ int linrec_launch(const float* q, const float* k, int64_t qk_bs, int64_t qk_ts, 
         set_error("too many q/k groups: %d", groups);
         return -18;
     }
+    const bool qk_aligned = qk_bs % 4 == 0 && qk_ts % 4 == 0 && qk_gs % 4 == 0 &&
+                            reinterpret_cast<uintptr_t>(q) % 16 == 0 && reinterpret_cast<uintptr_t>(k) % 16 == 0;
+    const unsigned flags = (decay ? kRecGated : 0) | ((w && !normalise) ? kRecW : 0) | (skip ? kRecSkip : 0) |
+                           (phi ? kRecPhi : 0) | (normalise ? kRecNormalise : 0) | (k_scale != 1.0f ? kRecKScale : 0) |
+                           (qk_aligned ? kRecAligned : 0);
+    const int path = linrec_path(d_state, cols_per_group, cols_per_decay, flags);
     // un-gated form on the matrix cores (no skip term, d_state <= 128, 16-byte aligned q / k rows)
-    if (decay == nullptr && skip == nullptr && d_state % 4 == 0 && d_state <= 128 && qk_bs % 4 == 0 && qk_ts % 4 == 0 &&
-        qk_gs % 4 == 0 && reinterpret_cast<uintptr_t>(q) % 16 == 0 && reinterpret_cast<uintptr_t>(k) % 16 == 0 &&
-        !getenv("EGS_REC_VALU")) {
+    if (path == 1) {
 #define EGS_CHUNK_ARGS                                                                                                  \
     q, k, qk_bs, qk_ts, qk_gs, v, v_bs, v_ts, normalise ? nullptr : w, y, batch, seqlen, channels, groups, cols_per_group, \
         d_state, phi, k_scale, normalise, stream
@@ -668,6 +929,18 @@ int linrec_launch(const float* q, const float* k, int64_t qk_bs, int64_t qk_ts, 
         if (j4 <= 16) return linattn_chunk_mfma_launch<16>(EGS_CHUNK_ARGS);
         return linattn_chunk_mfma_launch<32>(EGS_CHUNK_ARGS);
 #undef EGS_CHUNK_ARGS
+    }
+    // gated form (Mamba-2 SSD) on the matrix cores: a wave's 32 channels must share one decay head; no w, no phi
+    if (path == 2) {
+#define EGS_SSD_ARGS                                                                                               \
+    q, k, qk_bs, qk_ts, qk_gs, v, v_bs, v_ts, decay, vscale, skip, y, batch, seqlen, channels, groups, cols_per_group, \
+        cols_per_decay, d_state, stream
+        const int j4 = d_state / 4;
+        if (j4 <= 4) return ssd_chunk_mfma_launch<4>(EGS_SSD_ARGS);
+        if (j4 <= 8) return ssd_chunk_mfma_launch<8>(EGS_SSD_ARGS);
+        if (j4 <= 16) return ssd_chunk_mfma_launch<16>(EGS_SSD_ARGS);
+        return ssd_chunk_mfma_launch<32>(EGS_SSD_ARGS);
+#undef EGS_SSD_ARGS
     }
     const RecTiling tl = linrec_tiling(batch, channels, cols_per_group, d_state);
     const size_t need_ws = linrec_workspace_bytes(batch, seqlen, channels, cols_per_group, d_state);

@@ -38,6 +38,7 @@ int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, con
                     size_t, hipStream_t);
 int threshold_hist_launch(const void*, int, int, int64_t, int64_t, int64_t, const double*, int, double*, hipStream_t);
 size_t linrec_workspace_bytes(int64_t, int64_t, int, int, int);
+int linrec_path(int, int, int, unsigned);
 int softmax_attn_fwd_launch(const float*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, float*,
                             int64_t, int64_t, int, int, int, float, hipStream_t);
 int linrec_launch(const float*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, const float*,
@@ -243,13 +244,12 @@ int egs_threshold_hist(const void* vals, int dtype, int transform, int64_t outer
                                  as_stream(stream));
 }
 
-size_t egs_linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int d_state,
-                                  int gated_or_skip, int qk_aligned) {
-    if (batch <= 0 || seqlen <= 0 || channels <= 0 || cols_per_group <= 0 || d_state <= 0 ||
+size_t egs_linrec_workspace_bytes(int64_t batch, int64_t seqlen, int channels, int cols_per_group, int cols_per_decay,
+                                  int d_state, unsigned flags) {
+    if (batch <= 0 || seqlen <= 0 || channels <= 0 || cols_per_group <= 0 || cols_per_decay <= 0 || d_state <= 0 ||
         channels % cols_per_group != 0)
         return 512;
-    if (!gated_or_skip && qk_aligned && d_state % 4 == 0 && d_state <= 128 && !getenv("EGS_REC_VALU"))
-        return 512;                                                   // matrix-core path: no scratch
+    if (linrec_path(d_state, cols_per_group, cols_per_decay, flags) != 0) return 512;   // matrix-core paths: no scratch
     return linrec_workspace_bytes(batch, seqlen, channels, cols_per_group, d_state);
 }
 

@@ -288,8 +288,10 @@ def linear_recurrence_fwd(q, k, v, decay=None, vscale=None, w=None, skip=None, p
     if batch == 0 or seqlen == 0:
         return y
     aligned = (q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0 and all(st % 4 == 0 for st in q.stride()[:3]))
-    need = lib().egs_linrec_workspace_bytes(batch, seqlen, channels, cpg, d_state,
-                                            1 if (decay is not None or skip is not None) else 0, 1 if aligned else 0)
+    flags = ((1 if decay is not None else 0) | (2 if (w is not None and not normalise) else 0) |
+             (4 if skip is not None else 0) | (8 if phi else 0) | (16 if normalise else 0) |
+             (32 if float(k_scale) != 1.0 else 0) | (64 if aligned else 0))             # EGS_REC_* of eigspec.h
+    need = lib().egs_linrec_workspace_bytes(batch, seqlen, channels, cpg, cpd, d_state, flags)
     ws = _workspace(v.device, need)
     with torch.cuda.device(v.device):
         check(lib().egs_linear_recurrence_fwd(

@@ -297,3 +297,35 @@ def test_linear_recurrence_chunked_matrix_core_path(gpu_ops, monkeypatch, shape,
     monkeypatch.setenv("EGS_REC_VALU", "1")
     valu = gpu_ops.linear_recurrence_fwd(*args, phi=phi, normalise=(mode == "normalise"), **kw).cpu().numpy()
     close(got, valu, rtol=3e-5)
+
+
+@pytest.mark.parametrize("shape", [
+    # B, L, H, P (headdim), N (d_state), G (B/C groups)
+    (2, 16, 4, 32, 16, 1),      # one chunk, Mamba-2 C3-like heads
+    (3, 53, 2, 64, 64, 1),      # ragged chunk, 64-wide heads (two waves per head)
+    (1, 130, 8, 32, 128, 1),    # 256 channels: two channel chunks per group, d = 128
+    (2, 40, 4, 32, 8, 2),       # two B/C groups
+    (2, 33, 3, 32, 20, 1),      # d % 16 != 0, 96 channels (one idle wave)
+])
+def test_ssd_chunked_matrix_core_path(gpu_ops, monkeypatch, shape):
+    """Gated recurrence (Mamba-2 SSD) chunk-wise on the matrix cores against the oracle and the token-by-token kernel,
+    including strong decays (a ~ e^-8 per token) and a decay of exactly zero."""
+    B, L, H, P, N, G = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal((B, L, H, P)).astype(np.float32)
+    dt = np.log1p(np.exp(rng.standard_normal((B, L, H)) * 1.5)).astype(np.float32)
+    A = -rng.uniform(0.5, 16, H).astype(np.float32)
+    Bm = rng.standard_normal((B, L, G, N)).astype(np.float32)
+    Cm = rng.standard_normal((B, L, G, N)).astype(np.float32)
+    D = rng.standard_normal(H).astype(np.float32)
+    decay = np.exp(dt * A[None, None, :]).astype(np.float32)
+    decay[0, L // 2, 0] = 0.0                                          # hard reset of one head
+    skip = np.repeat(D, P)
+    want = BO.linear_recurrence(Cm, Bm, x.reshape(B, L, H * P), decay=decay, vscale=dt, skip=skip, cols_per_decay=P)
+    args = (dev(Cm), dev(Bm), dev(x.reshape(B, L, H * P)))
+    kw = dict(decay=dev(decay), vscale=dev(dt), skip=dev(skip), cols_per_decay=P)
+    got = gpu_ops.linear_recurrence_fwd(*args, **kw).cpu().numpy()
+    close(got, want, rtol=5e-5)
+    monkeypatch.setenv("EGS_REC_VALU", "1")
+    valu = gpu_ops.linear_recurrence_fwd(*args, **kw).cpu().numpy()
+    close(got, valu, rtol=5e-5)
