@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void ssd_chunk_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t bs, int64_t ts, int64_t gs,
     const float* __restrict__ v, int64_t v_bs, int64_t v_ts, const float* __restrict__ decay,
     const float* __restrict__ vscale, const float* __restrict__ skip, float* __restrict__ y, int64_t L, int channels,
-    int groups, int cpg, int cpd, int d) {
+    int groups, int cpg, int cpd, int d, int vvec) {
     constexpr int DT = J / 4;
     constexpr int kLdj = J + 4, kLdq = 4 * J + 4, kLdk = 4 * J + 16, kLdv = 128 + 16;
     constexpr int XQ = (J + 15) / 16;
@@ -608,6 +608,15 @@ __global__ __launch_bounds__(256) void ssd_chunk_mfma_kernel(
     float* yb = y + b * L * channels + (int64_t)grp * cpg + cc0;
     const int st = tid >> 4, sf = tid & 15;                           // staging role: token, float4 slot
     const int ch0 = grp * cpg + cc0;                                  // first channel of this workgroup
+    // token-independent parts of the fetch addresses (head of the two v float4 slots, head of wave sf)
+    int vcol[2], vhead[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int f = sf + 16 * x;
+        vcol[x] = (4 * f < cw) ? 4 * f : cw - 4;                     // cw is a multiple of 32 on this path
+        vhead[x] = (ch0 + vcol[x]) / cpd;
+    }
+    const int lhead = (ch0 + ((32 * (sf & 3) < cw) ? 32 * (sf & 3) : cw - 1)) / cpd;
 
     // operands of a chunk, fetched TWO chunks ahead (the per-chunk work is short for small d_state, so one chunk of
     // compute does not cover the HBM latency)
@@ -630,21 +639,19 @@ __global__ __launch_bounds__(256) void ssd_chunk_mfma_kernel(
             qpre[x] = *reinterpret_cast<const float4*>(qb + t * ts + off);
             kpre[x] = *reinterpret_cast<const float4*>(kb + t * ts + off);
         }
+        const float* vrow = vb + t * v_ts;
+        const float* srow = vscale + (b * L + t) * nh;
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            const int f = sf + 16 * x;
-            const float* src = vb + t * v_ts;
-            float e[4];
-#pragma unroll
-            for (int z = 0; z < 4; ++z) e[z] = src[(4 * f + z < cw) ? 4 * f + z : cw - 1];
-            vpre[x] = make_float4(e[0], e[1], e[2], e[3]);
-            const int chn = ch0 + ((4 * f < cw) ? 4 * f : cw - 1);    // the 4 channels of a float4 share a head (cpd % 32 == 0)
-            spre[x] = vscale[(b * L + t) * nh + chn / cpd];
+            if (vvec) {                                               // uniform: 16-byte aligned value rows
+                vpre[x] = *reinterpret_cast<const float4*>(vrow + vcol[x]);
+            } else {
+                vpre[x] = make_float4(vrow[vcol[x]], vrow[vcol[x] + 1], vrow[vcol[x] + 2], vrow[vcol[x] + 3]);
+            }
+            spre[x] = srow[vhead[x]];                                 // the 4 channels of a float4 share a head
         }
-        if (sf < 4) {                                                 // log-decay of wave sf's head for token st
-            const int chn = ch0 + ((32 * sf < cw) ? 32 * sf : cw - 1);
-            lpre = __log2f(fmaxf(decay[(b * L + t) * nh + chn / cpd], 1.6e-38f));   // base 2: the factors are one v_exp_f32
-        }
+        if (sf < 4)                                                   // log-decay of wave sf's head for token st
+            lpre = __log2f(fmaxf(decay[(b * L + t) * nh + lhead], 1.6e-38f));   // base 2: the factors are one v_exp_f32
     };
     auto stage = [&](const Pre& pr, int64_t t0c) {
         const float4(&qpre)[XQ] = pr.q;
@@ -777,16 +784,19 @@ __global__ __launch_bounds__(256) void ssd_chunk_mfma_kernel(
                 S[dt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, vB[kk][1], S[dt][1], 0, 0, 0);
             }
         }
+        const bool full = (t0 + 16 <= L) && (cw == 128);              // uniform: no predication needed
+        float* yrow = yb + (t0 + 4 * g) * channels + col0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t trow = t0 + 4 * g + r;
-            if (trow < L) {
-                const float er = __builtin_amdgcn_exp2f(l_row[r]);
-                if (col0 < cw)
-                    yb[trow * channels + col0] = fmaf(er, Yi[0][r], Y[0][r]) + sk0 * Vraw[(4 * g + r) * kLdv + col0];
-                if (col0 + 16 < cw)
-                    yb[trow * channels + col0 + 16] =
-                        fmaf(er, Yi[1][r], Y[1][r]) + sk1 * Vraw[(4 * g + r) * kLdv + col0 + 16];
+            const float er = __builtin_amdgcn_exp2f(l_row[r]);
+            const float o0 = fmaf(er, Yi[0][r], Y[0][r]) + sk0 * Vraw[(4 * g + r) * kLdv + col0];
+            const float o1 = fmaf(er, Yi[1][r], Y[1][r]) + sk1 * Vraw[(4 * g + r) * kLdv + col0 + 16];
+            if (full) {
+                yrow[r * channels] = o0;
+                yrow[r * channels + 16] = o1;
+            } else if (t0 + 4 * g + r < L) {
+                if (col0 < cw) yrow[r * channels] = o0;
+                if (col0 + 16 < cw) yrow[r * channels + 16] = o1;
             }
         }
     };
@@ -808,8 +818,9 @@ static int ssd_chunk_mfma_launch(const float* q, const float* k, int64_t bs, int
         EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ssd_chunk_mfma_kernel<J>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     const dim3 grid((unsigned)(((cpg + 127) / 128) * groups), (unsigned)batch);
+    const int vvec = (v_bs % 4 == 0 && v_ts % 4 == 0 && cpg % 4 == 0 && reinterpret_cast<uintptr_t>(v) % 16 == 0) ? 1 : 0;
     hipLaunchKernelGGL(ssd_chunk_mfma_kernel<J>, grid, dim3(256), dyn, stream, q, k, bs, ts, gs, v, v_bs, v_ts, decay, vscale,
-                       skip, y, L, channels, groups, cpg, cpd, d);
+                       skip, y, L, channels, groups, cpg, cpd, d, vvec);
     EGS_LAUNCH_CHECK();
     return 0;
 }
