@@ -210,6 +210,14 @@ int egs_softmax_attention_fwd(const float* q, const float* k, int64_t qk_batch_s
                               float* y, int64_t batch, int64_t seqlen, int num_heads, int head_dim, int v_dim,
                               float scale, egs_stream_t stream);
 
+/* ---- 8(f) rank 4: softmax eta from q, k that already exist (forward hooks on a language model's q_proj / k_proj) --
+ * Replaces get_eig_from_qkv_att_softmax (notebooks/lm_eigvals.ipynb, cell 13): the arithmetic of get_eig_att_softmax
+ * without the projection.  qk : float[B, L, 2 d_qk] = per token the H query heads followed by the H key heads (grouped
+ * query attention: the caller repeats each key head H / H_kv times); eta : double[B, L-1, H]. */
+size_t egs_softmax_eta_qk_workspace_bytes(int64_t batch, int64_t seqlen, int num_heads);
+int egs_softmax_eta_qk(const float* qk, int64_t batch, int64_t seqlen, int d_qk, int num_heads, double* eta,
+                       void* workspace, size_t workspace_bytes, egs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ from __future__ import annotations
 import numpy as np
 
 __all__ = [
-    "linear_f32", "eta_softmax", "eta_linear", "eta_linear_streaming", "eta_norm",
+    "linear_f32", "eta_softmax", "eta_softmax_from_qk", "eta_linear", "eta_linear_streaming", "eta_norm",
     "lambda_mamba2", "lambda_mamba2_lti",
     "discrete_dplr", "s4_dplr_ab", "s4_column_inputs", "eigvals_ssm", "lambda_lru", "lambda_s5",
     "radius", "phase_deg", "threshold_analysis", "threshold_analysis_ssm",
@@ -432,3 +432,22 @@ def max_abs_dlambda(w_a, w_b):
         r, c = linear_sum_assignment(cost)
         worst = max(worst, float(cost[r, c].max()))
     return worst
+
+
+def eta_softmax_from_qk(q, k):
+    """notebooks/lm_eigvals.ipynb cell 13 (get_eig_from_qkv_att_softmax): the arithmetic of eta_softmax starting from
+    q, k [B, L, H, hd] (fp32 scores, zero mask, row max over the masked row, fp64 exp / sum).  Returns
+    (B, L-1, H, 1) float64."""
+    q = np.asarray(q, _f32)
+    k = np.asarray(k, _f32)
+    seqlen = q.shape[1]
+    scores = np.einsum("bthd,bshd->btsh", q, k).astype(_f32)
+    tril = np.tril(np.ones((seqlen, seqlen), _f32))
+    scores = scores * tril[None, :, :, None]
+    smax = scores.max(axis=2)                                       # over s, masked zeros included
+    smax_r = smax[:, :, None, :] * tril[None, :, :, None]
+    norm = (scores - smax_r).astype(_f32).astype(np.float64)
+    nu = np.nan_to_num(np.exp(norm)).sum(axis=2)
+    eta = nu[:, :-1, :] / nu[:, 1:, :]
+    diff = (-smax[:, 1:, :] + smax[:, :-1, :]).astype(_f32)
+    return (eta * np.exp(diff.astype(np.float64)))[..., None]

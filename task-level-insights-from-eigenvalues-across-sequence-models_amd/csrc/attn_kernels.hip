@@ -682,6 +682,24 @@ static int softmax_nu_mfma_launch(const float* qk, int64_t nb, int64_t seqlen, i
     return 0;
 }
 
+// row statistics of the causal score matrix for nb sequences of a packed [nb, L, 2 d_qk] (q | k) buffer
+static int softmax_nu_dispatch(const float* qk, int64_t nb, int64_t seqlen, int d_qk, int num_heads, double* nu, float* mrow,
+                               hipStream_t stream) {
+    const int hd = d_qk / num_heads;
+    const int hd4 = (hd + 3) / 4;
+    if (hd % 4 == 0 && d_qk % 4 == 0 && hd4 <= 64 && (reinterpret_cast<uintptr_t>(qk) & 15) == 0 &&
+        !getenv("EGS_SOFTMAX_VALU")) {                                // matrix-core tiles
+        if (hd4 <= 4) return softmax_nu_mfma_launch<4>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+        if (hd4 <= 8) return softmax_nu_mfma_launch<8>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+        if (hd4 <= 16) return softmax_nu_mfma_launch<16>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+        if (hd4 <= 32) return softmax_nu_mfma_launch<32>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+        return softmax_nu_mfma_launch<64>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+    }
+    const dim3 sgrid((unsigned)((seqlen + kTT - 1) / kTT), (unsigned)num_heads, (unsigned)nb);
+    hipLaunchKernelGGL(softmax_nu_kernel, sgrid, dim3(256), 0, stream, qk, seqlen, d_qk, num_heads, nu, mrow);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // 3. eta[b, t, h] from nu[b, h, t] (and m[b, h, t] for softmax)
 // ---------------------------------------------------------------------------------------------------
@@ -802,19 +820,8 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
                                n_cols, qk);
         EGS_LAUNCH_CHECK();
         if (softmax) {
-            const int hd4 = (hd + 3) / 4;
-            if (hd % 4 == 0 && d_qk % 4 == 0 && hd4 <= 64 && !getenv("EGS_SOFTMAX_VALU")) {   // matrix-core tiles
-                int st = 0;
-                if (hd4 <= 4) st = softmax_nu_mfma_launch<4>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
-                else if (hd4 <= 8) st = softmax_nu_mfma_launch<8>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
-                else if (hd4 <= 16) st = softmax_nu_mfma_launch<16>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
-                else if (hd4 <= 32) st = softmax_nu_mfma_launch<32>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
-                else st = softmax_nu_mfma_launch<64>(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
-                if (st) return st;
-            } else {
-                const dim3 sgrid((unsigned)((seqlen + kTT - 1) / kTT), (unsigned)num_heads, (unsigned)nb);
-                hipLaunchKernelGGL(softmax_nu_kernel, sgrid, dim3(256), 0, stream, qk, seqlen, d_qk, num_heads, nu, mrow);
-            }
+            const int st = softmax_nu_dispatch(qk, nb, seqlen, d_qk, num_heads, nu, mrow, stream);
+            if (st) return st;
         } else {
             const int64_t tasks = nb * num_heads * nchunks;
             const unsigned grid = (unsigned)((tasks + 3) / 4);
@@ -837,6 +844,32 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
                            nb, seqlen, num_heads, softmax ? 1 : 0, eta + b0 * (seqlen - 1) * num_heads);
         EGS_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// softmax eta from q, k that already exist (hooked projections of a language model, notebooks/lm_eigvals.ipynb cell 13):
+// qk is the packed [B, L, 2 d_qk] buffer; scratch = nu (fp64) + row maxima (fp32) for the whole batch
+size_t softmax_eta_qk_workspace_bytes(int64_t batch, int64_t seqlen, int num_heads) {
+    return (size_t)batch * num_heads * seqlen * (sizeof(double) + sizeof(float)) + 512;
+}
+
+int softmax_eta_qk_launch(const float* qk, int64_t batch, int64_t seqlen, int d_qk, int num_heads, double* eta,
+                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (batch == 0 || seqlen <= 1) return 0;
+    if (workspace_bytes < softmax_eta_qk_workspace_bytes(batch, seqlen, num_heads)) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, softmax_eta_qk_workspace_bytes(batch, seqlen, num_heads));
+        return -7;
+    }
+    double* nu = static_cast<double*>(workspace);
+    float* mrow = reinterpret_cast<float*>(nu + batch * num_heads * seqlen);
+    const int st = softmax_nu_dispatch(qk, batch, seqlen, d_qk, num_heads, nu, mrow, stream);
+    if (st) return st;
+    EGS_LAUNCH_CHECK();
+    const int64_t total = batch * (seqlen - 1) * num_heads;
+    const int64_t fb = (total + 255) / 256;
+    hipLaunchKernelGGL(eta_finalize_kernel, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(256), 0, stream, nu, mrow, batch,
+                       seqlen, num_heads, 1, eta);
+    EGS_LAUNCH_CHECK();
     return 0;
 }
 

@@ -39,6 +39,8 @@ int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, con
 int threshold_hist_launch(const void*, int, int, int64_t, int64_t, int64_t, const double*, int, double*, hipStream_t);
 size_t linrec_workspace_bytes(int64_t, int64_t, int, int, int);
 int linrec_path(int, int, int, unsigned);
+size_t softmax_eta_qk_workspace_bytes(int64_t, int64_t, int);
+int softmax_eta_qk_launch(const float*, int64_t, int64_t, int, int, double*, void*, size_t, hipStream_t);
 int softmax_attn_fwd_launch(const float*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, float*,
                             int64_t, int64_t, int, int, int, float, hipStream_t);
 int linrec_launch(const float*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, const float*,
@@ -293,6 +295,24 @@ int egs_softmax_attention_fwd(const float* q, const float* k, int64_t qk_batch_s
     return softmax_attn_fwd_launch(q, k, qk_batch_stride, qk_token_stride, qk_head_stride, v, v_batch_stride,
                                    v_token_stride, y, batch, seqlen, num_heads, head_dim, v_dim, scale,
                                    as_stream(stream));
+}
+
+size_t egs_softmax_eta_qk_workspace_bytes(int64_t batch, int64_t seqlen, int num_heads) {
+    if (batch <= 0 || seqlen <= 0 || num_heads <= 0) return 512;
+    return softmax_eta_qk_workspace_bytes(batch, seqlen, num_heads);
+}
+
+int egs_softmax_eta_qk(const float* qk, int64_t batch, int64_t seqlen, int d_qk, int num_heads, double* eta,
+                       void* workspace, size_t workspace_bytes, egs_stream_t stream) {
+    EGS_ARG(batch >= 0 && batch <= 65535, 2);
+    EGS_ARG(seqlen >= 0, 3);
+    EGS_ARG(d_qk > 0, 4);
+    EGS_ARG(num_heads > 0 && d_qk % num_heads == 0 && num_heads <= 65535, 5);
+    if (batch == 0 || seqlen <= 1) return 0;
+    EGS_ARG(qk != nullptr, 1);
+    EGS_ARG(eta != nullptr, 6);
+    EGS_ARG(workspace != nullptr, 7);
+    return softmax_eta_qk_launch(qk, batch, seqlen, d_qk, num_heads, eta, workspace, workspace_bytes, as_stream(stream));
 }
 
 }  // extern "C"

@@ -326,3 +326,32 @@ def softmax_attention_fwd(q, k, v, scale=None):
                                               v.stride(0), v.stride(1), _ptr(y), batch, seqlen, heads, hd, dv, sc,
                                               _stream()), "egs_softmax_attention_fwd")
     return y
+
+
+# ---- notebook path ------------------------------------------------------------------
+def softmax_eta_from_qk(q, k):
+    """Softmax-attention eta from existing q, k: q [B, L, H, hd], k [B, L, H_kv, hd] with H % H_kv == 0 (grouped-query
+    attention: query head h reads key head h // (H / H_kv), the transformers ``repeat_kv`` convention).  Any float
+    dtype (computed in fp32 / fp64 like the eta path); returns float64 [B, L-1, H].
+    Replaces get_eig_from_qkv_att_softmax of notebooks/lm_eigvals.ipynb (cell 13)."""
+    _require_cuda(q, "q")
+    _require_cuda(k, "k")
+    if q.dim() != 4 or k.dim() != 4 or q.shape[:2] != k.shape[:2] or q.shape[3] != k.shape[3]:
+        raise ValueError(f"expected q [B, L, H, hd] and k [B, L, H_kv, hd], got {tuple(q.shape)} and {tuple(k.shape)}")
+    batch, seqlen, heads, hd = q.shape
+    kv = k.shape[2]
+    if kv == 0 or heads % kv != 0:
+        raise ValueError(f"num_heads ({heads}) must be a multiple of num_kv_heads ({kv})")
+    if kv != heads:
+        k = k.repeat_interleave(heads // kv, dim=2)
+    qk = torch.cat([q.reshape(batch, seqlen, heads * hd).float(), k.reshape(batch, seqlen, heads * hd).float()], dim=-1)
+    qk = qk.contiguous()
+    eta = torch.empty((batch, max(seqlen - 1, 0), heads), dtype=torch.float64, device=q.device)
+    if batch == 0 or seqlen <= 1:
+        return eta
+    need = lib().egs_softmax_eta_qk_workspace_bytes(batch, seqlen, heads)
+    ws = _workspace(q.device, need)
+    with torch.cuda.device(q.device):
+        check(lib().egs_softmax_eta_qk(_ptr(qk), batch, seqlen, heads * hd, heads, _ptr(eta), _ptr(ws),
+                                       ws.numel() * ws.element_size(), _stream()), "egs_softmax_eta_qk")
+    return eta

@@ -200,3 +200,13 @@ def test_dense_eig_similarity_known_spectrum():
     V = np.eye(n) + 0.1 * rng.standard_normal((n, n)) / np.sqrt(n)
     A = V @ Dm @ np.linalg.inv(V)
     assert O.max_abs_dlambda(O.eigvals_dense(A), lam) < 1e-12
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_notebook_softmax_eta_from_qk_golden(golden, case):
+    """oracle.eta_softmax_from_qk against the reference notebook's own get_eig_from_qkv_att_softmax (cell 13)."""
+    g = golden("notebook")
+    got = O.eta_softmax_from_qk(g[f"q_{case}"], g[f"k_{case}"])
+    want = g[f"eta_{case}"]
+    assert got.shape == want.shape and got.dtype == np.float64
+    np.testing.assert_allclose(got, want, rtol=3e-5)
