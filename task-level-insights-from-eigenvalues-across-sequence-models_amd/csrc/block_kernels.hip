@@ -35,7 +35,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRecT = 4;          // tokens per block (prefetch / LDS exchange granularity)
 constexpr int kRecPad = 8;        // record streams are zero-padded to a multiple of this many tokens
 
-__device__ __forceinline__ float phi_elu1(float x) { return x > 0.0f ? x + 1.0f : __expf(x); }
 
 // raw strided q, k  ->  compact, transformed, zero-padded stream  [B][G][RS][L][2 (q, k)][DR]:
 // the wave that owns state rows [r DR, (r+1) DR) reads one contiguous 2 DR-float record per token.
