@@ -329,3 +329,47 @@ def test_ssd_chunked_matrix_core_path(gpu_ops, monkeypatch, shape):
     monkeypatch.setenv("EGS_REC_VALU", "1")
     valu = gpu_ops.linear_recurrence_fwd(*args, **kw).cpu().numpy()
     close(got, valu, rtol=5e-5)
+
+
+def test_mixers_randomised_shapes(gpu_ops):
+    """Forty random small configurations (ragged lengths, odd head counts / widths, gated and un-gated, both kernel
+    families) against the oracle: shape handling, tails and padding of every path."""
+    rng = np.random.default_rng(2027)
+    for it in range(40):
+        B = int(rng.integers(1, 4))
+        L = int(rng.integers(1, 70))
+        G = int(rng.integers(1, 4))
+        d = int(rng.choice([3, 4, 8, 12, 16, 20, 32, 64, 100, 128, 132]))
+        gated = bool(rng.integers(0, 2))
+        if gated:
+            cpd = int(rng.choice([4, 16, 32, 64]))
+            heads_per_group = int(rng.integers(1, 4))
+            cpg = cpd * heads_per_group
+        else:
+            cpg = int(rng.choice([1, 5, 16, 32, 48, 64, 130]))
+            cpd = cpg
+        C = G * cpg
+        q = (rng.standard_normal((B, L, G, d)) / np.sqrt(d)).astype(np.float32)
+        k = (rng.standard_normal((B, L, G, d)) / np.sqrt(d)).astype(np.float32)
+        v = rng.standard_normal((B, L, C)).astype(np.float32)
+        kw, okw = {}, {}
+        if gated:
+            nh = C // cpd
+            a = rng.uniform(0.0, 1.0, (B, L, nh)).astype(np.float32)
+            s = rng.uniform(0.01, 1.0, (B, L, nh)).astype(np.float32)
+            kw.update(decay=dev(a), vscale=dev(s), cols_per_decay=cpd)
+            okw.update(decay=a, vscale=s, cols_per_decay=cpd)
+            if rng.integers(0, 2):
+                sk = rng.standard_normal(C).astype(np.float32)
+                kw["skip"], okw["skip"] = dev(sk), sk
+        elif rng.integers(0, 2):
+            w = rng.uniform(0.5, 2.0, (B, L, G)).astype(np.float32)
+            kw["w"], okw["w"] = dev(w), w
+        want = BO.linear_recurrence(q, k, v, **okw)
+        got = gpu_ops.linear_recurrence_fwd(dev(q), dev(k), dev(v), **kw)
+        close(got, want, rtol=5e-5, atol=1e-6)
+        # softmax attention on the same q / k (as heads), value width = cpg
+        H, hd = G, d
+        y = gpu_ops.softmax_attention_fwd(dev(q), dev(k), dev(v))
+        want_sm = BO.softmax_attention(np.stack([q, k], axis=2), v.reshape(B, L, H, cpg))
+        close(y.reshape(B, L, H, cpg), want_sm, rtol=5e-5, atol=1e-6)
