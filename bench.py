@@ -150,7 +150,7 @@ def main():
     # ---- per-kernel timing (HIP events on the launch stream) for the roofline object ----
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     hq_ms, hs_ms = [], []
-    chunk = min(nmat, 16384)
+    chunk = min(nmat, 65536)             # the launch size the step uses (egs_eig_workspace_bytes: 64 Ki matrices)
     hbuf = torch.empty((chunk, n, n), dtype=torch.float64, device=device)
     lib = pkg._capi.lib()
     import ctypes
@@ -180,12 +180,13 @@ def main():
     hs_flops = (10.0 / 3.0) * n ** 3 * chunk
     achieved_tf = qr_flops / (hq_avg * 1e-3) / 1e12
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be read from
-    # inside the process; collected with rocprofv3 --pmc on this same command at the same launch size, 16384 matrices)
+    # inside the process; collected with rocprofv3 --pmc on this same command at 16384 and 65536 matrices per launch --
+    # the bytes per matrix agree, the kernel reads each Hessenberg matrix once)
     traffic = None
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if chunk == 16384 and n == 64:
-            traffic = tr["kernels"]["hqr_real_kernel"]["hbm_bytes_per_launch"]
+        if n == 64:
+            traffic = tr["kernels"]["hqr_real_kernel"]["hbm_bytes_per_matrix"] * chunk
     except Exception:
         pass
     roofline = {

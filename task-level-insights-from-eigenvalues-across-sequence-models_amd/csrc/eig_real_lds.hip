@@ -785,7 +785,9 @@ __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict_
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------
 size_t eig_real_lds_workspace_bytes(int64_t nmat, int n) {
-    const int64_t chunk = nmat < 16384 ? nmat : 16384;
+    // Hessenberg matrices of one chunk.  64 Ki matrices per launch (2 GiB at n = 64): every launch ends with a tail in
+    // which the slowest matrices keep a few CUs busy; 4x fewer launches than with 16 Ki chunks measured 2.6 % faster
+    const int64_t chunk = nmat < 65536 ? nmat : 65536;
     return (size_t)chunk * n * n * sizeof(double);
 }
 
