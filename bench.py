@@ -156,6 +156,7 @@ def main():
     import ctypes
     wtmp = torch.empty((chunk, n), dtype=torch.complex128, device=device)
     itmp = torch.empty((chunk,), dtype=torch.int32, device=device)
+    qbuf = torch.zeros((32,), dtype=torch.int64, device=device)       # work-queue counter of the QR kernel
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     nlaunch = 0
     for rep in range(2):
@@ -166,7 +167,7 @@ def main():
                                        ctypes.c_void_p(hbuf.data_ptr()), stream)
             ev[1].record()
             lib.egs_hseqr_batched(ctypes.c_void_p(hbuf.data_ptr()), cnt, n, ctypes.c_void_p(wtmp.data_ptr()),
-                                  ctypes.c_void_p(itmp.data_ptr()), stream)
+                                  ctypes.c_void_p(itmp.data_ptr()), ctypes.c_void_p(qbuf.data_ptr()), stream)
             ev[2].record()
             ev[2].synchronize()
             if rep == 1 and cnt == chunk:

@@ -97,10 +97,13 @@ int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int l
  * xGEHRD / xHSEQR so that callers (and bench.py) can time or reuse them individually.
  *   egs_hessenberg_batched : a -> h, double[nmat, n, n] row-major upper-Hessenberg (exact zeros below the
  *                            subdiagonal); same eigenvalues as a.
- *   egs_hseqr_batched      : h (as produced above) -> w, info. */
+ *   egs_hseqr_batched      : h (as produced above) -> w, info.  `queue` is NULL or 8 bytes of device scratch: with
+ *                            it the kernel runs as one resident set of wavefronts that take matrices from a work
+ *                            queue (what egs_eig_general_batched does); without it, one matrix per wavefront. */
 int egs_hessenberg_batched(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h,
                            egs_stream_t stream);
-int egs_hseqr_batched(const double* h, int64_t nmat, int n, double* w, int32_t* info, egs_stream_t stream);
+int egs_hseqr_batched(const double* h, int64_t nmat, int n, double* w, int32_t* info, void* queue,
+                      egs_stream_t stream);
 
 /* ---- K2: Mamba-2 per-token transition scalars -----------------------------------------------------
  * Replaces get_eig_mamba2 (analysis/eval_eig.py:176-190): only the last `nheads` rows of in_proj.weight

@@ -49,7 +49,7 @@ int linrec_launch(const float*, const float*, int64_t, int64_t, int64_t, const f
 size_t eig_real_lds_workspace_bytes(int64_t, int);
 int eig_real_lds_launch(const double*, int64_t, int, int, int64_t, double*, int32_t*, void*, size_t, hipStream_t);
 int hess_real_launch(const double*, int64_t, int, int, int64_t, double*, int32_t*, hipStream_t);
-int hqr_real_launch(const double*, int64_t, int, double*, int32_t*, int, hipStream_t);
+int hqr_real_launch(const double*, int64_t, int, double*, int32_t*, int, hipStream_t, unsigned long long*);
 size_t eig_cplx_workspace_bytes(int64_t, int);
 int eig_cplx_launch(const void*, bool, int64_t, int, int, int64_t, double*, int32_t*, void*, size_t, hipStream_t);
 
@@ -142,14 +142,15 @@ int egs_hessenberg_batched(const double* a, int64_t nmat, int n, int lda, int64_
     return hess_real_launch(a, nmat, n, lda, stride, h, nullptr, as_stream(stream));   // no scaling: h ~ a exactly
 }
 
-int egs_hseqr_batched(const double* h, int64_t nmat, int n, double* w, int32_t* info, egs_stream_t stream) {
+int egs_hseqr_batched(const double* h, int64_t nmat, int n, double* w, int32_t* info, void* queue,
+                      egs_stream_t stream) {
     EGS_ARG(nmat >= 0, 2);
     EGS_ARG(n >= 0 && n <= 64, 3);
     if (nmat == 0 || n == 0) return 0;
     EGS_ARG(h != nullptr, 1);
     EGS_ARG(w != nullptr, 4);
     EGS_ARG(info != nullptr, 5);
-    return hqr_real_launch(h, nmat, n, w, info, 0, as_stream(stream));
+    return hqr_real_launch(h, nmat, n, w, info, 0, as_stream(stream), static_cast<unsigned long long*>(queue));
 }
 
 int egs_mamba2_lambda(const float* x, int64_t ntok, int d_model, int64_t ldx, const float* w_dt, const float* b_dt,

@@ -754,30 +754,46 @@ __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ sr
 
 __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
                                                        double* __restrict__ w, int32_t* __restrict__ info,
-                                                       int waves_per_block, int scaled) {
+                                                       int waves_per_block, int scaled,
+                                                       unsigned long long* __restrict__ next_mat) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    const int64_t mat = (int64_t)blockIdx.x * waves_per_block + wave;
-    if (mat >= nmat) return;
     const int ldp = hqr_pair_ld(n);
     double* base = smem + (size_t)(wave >> 1) * ((size_t)n * ldp);
-    const double* src = hin + mat * (int64_t)n * n;
-    double* wo = w + mat * 2 * (int64_t)n;
-    // when the Hessenberg stage scaled the matrix, info[mat] carries the power-of-two exponent to undo
-    if (scaled && info[mat] == kNonFinite) {     // like numpy.linalg.eigvals, non-finite input is an error, not a spectrum
-        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int j = lane; j < 2 * n; j += kWave) wo[j] = qnan;
-        if (lane == 0) info[mat] = n;
-        return;
-    }
-    const double rescale = scaled ? scalbn(1.0, info[mat]) : 1.0;
-    if (n == 64) {
-        if ((wave & 1) == 0) hqr_run(MatViewT<71, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
-        else hqr_run(MatViewT<71, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
-    } else {
-        if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
-        else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
+    // persistent waves with a work queue: the launch fills the chip exactly once (2 workgroups per CU); a wave that has
+    // finished its matrix takes the next unclaimed one from a global counter, so nobody waits for the slowest matrix of
+    // a workgroup and the kernel's tail is one matrix long.  (A static grid-stride assignment measured 4 % SLOWER than
+    // plain one-matrix-per-wave workgroups: the unluckiest of 2048 static partitions sets the kernel time.)  No
+    // workgroup barriers are used and a wave reloads only its own half of the pair array.  Every wave leaves the loop
+    // when the counter passes nmat.  next_mat == null: one matrix per wave (the grid covers all matrices).
+    const int64_t first = (int64_t)blockIdx.x * waves_per_block + wave;
+    const int64_t stride0 = (int64_t)gridDim.x * waves_per_block;
+    for (int64_t mat = first; mat < nmat;) {
+        const double* src = hin + mat * (int64_t)n * n;
+        double* wo = w + mat * 2 * (int64_t)n;
+        // when the Hessenberg stage scaled the matrix, info[mat] carries the power-of-two exponent to undo
+        if (scaled && info[mat] == kNonFinite) {     // like numpy.linalg.eigvals, non-finite input is an error, not a spectrum
+            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+            for (int j = lane; j < 2 * n; j += kWave) wo[j] = qnan;
+            if (lane == 0) info[mat] = n;
+        } else {
+        const double rescale = scaled ? scalbn(1.0, info[mat]) : 1.0;
+        if (n == 64) {
+            if ((wave & 1) == 0) hqr_run(MatViewT<71, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
+            else hqr_run(MatViewT<71, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
+        } else {
+            if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
+            else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
+        }
+        }
+        wave_lds_sync();                                          // this matrix's LDS traffic is complete before the next load
+        if (next_mat == nullptr) break;
+        unsigned long long nx = 0ULL;
+        if (lane == 0) nx = atomicAdd(next_mat, 1ULL);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(nx & 0xffffffffULL));
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(nx >> 32));
+        mat = stride0 + (int64_t)(((unsigned long long)hi << 32) | lo);
     }
 }
 
@@ -788,7 +804,7 @@ size_t eig_real_lds_workspace_bytes(int64_t nmat, int n) {
     // Hessenberg matrices of one chunk.  64 Ki matrices per launch (2 GiB at n = 64): every launch ends with a tail in
     // which the slowest matrices keep a few CUs busy; 4x fewer launches than with 16 Ki chunks measured 2.6 % faster
     const int64_t chunk = nmat < 65536 ? nmat : 65536;
-    return (size_t)chunk * n * n * sizeof(double);
+    return (size_t)chunk * n * n * sizeof(double) + 256;          // + the work-queue counter of the QR kernel
 }
 
 static int set_lds_attrs() {
@@ -815,7 +831,8 @@ int hess_real_launch(const double* a, int64_t nmat, int n, int lda, int64_t stri
     return 0;
 }
 
-int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* info, int scaled, hipStream_t stream) {
+int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* info, int scaled, hipStream_t stream,
+                    unsigned long long* queue) {
     if (nmat == 0 || n == 0) return 0;
     int st = set_lds_attrs();
     if (st) return st;
@@ -832,9 +849,28 @@ int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* in
     }
     const int hqr_waves = 2 * pairs;
     const size_t hqr_lds = pairs * pair_bytes;
-    const unsigned gq = (unsigned)((nmat + hqr_waves - 1) / hqr_waves);
+    unsigned gq = (unsigned)((nmat + hqr_waves - 1) / hqr_waves);
+    if (queue != nullptr && !getenv("EGS_HQR_NONPERSISTENT")) {   // one resident wave set + work queue
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cus = prop.multiProcessorCount;
+            if (cus <= 0) cus = 256;
+        }
+        const unsigned resident = (unsigned)cus * (unsigned)((160 * 1024) / hqr_lds);
+        if (gq > resident) {
+            gq = resident;
+            EGS_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream));
+        } else {
+            queue = nullptr;
+        }
+    } else {
+        queue = nullptr;
+    }
     hipLaunchKernelGGL(hqr_real_kernel, dim3(gq), dim3(hqr_waves * kWave), hqr_lds, stream, h, nmat, n, w, info,
-                       hqr_waves, scaled);
+                       hqr_waves, scaled, queue);
     EGS_LAUNCH_CHECK();
     return 0;
 }
@@ -843,10 +879,10 @@ int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t s
                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (nmat == 0 || n == 0) return 0;
     const size_t per_mat = (size_t)n * n * sizeof(double);
-    int64_t chunk = (int64_t)(workspace_bytes / per_mat);
+    int64_t chunk = workspace_bytes > 256 ? (int64_t)((workspace_bytes - 256) / per_mat) : 0;
     if (chunk > nmat) chunk = nmat;
     if (chunk < 1) {
-        set_error("workspace too small: %zu bytes, need at least %zu", workspace_bytes, per_mat);
+        set_error("workspace too small: %zu bytes, need at least %zu", workspace_bytes, per_mat + 256);
         return -9;
     }
     double* hws = static_cast<double*>(workspace);
@@ -854,7 +890,8 @@ int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t s
         const int64_t cnt = (nmat - m0 < chunk) ? (nmat - m0) : chunk;
         int st = hess_real_launch(a + m0 * stride, cnt, n, lda, stride, hws, info + m0, stream);
         if (st) return st;
-        st = hqr_real_launch(hws, cnt, n, w + m0 * 2 * (int64_t)n, info + m0, 1, stream);
+        st = hqr_real_launch(hws, cnt, n, w + m0 * 2 * (int64_t)n, info + m0, 1, stream,
+                             reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + (size_t)chunk * per_mat));
         if (st) return st;
     }
     return 0;

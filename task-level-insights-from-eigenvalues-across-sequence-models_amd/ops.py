@@ -100,7 +100,8 @@ def hseqr_batched(h):
     w = torch.empty((nmat, n), dtype=torch.complex128, device=h.device)
     info = torch.empty((nmat,), dtype=torch.int32, device=h.device)
     with torch.cuda.device(h.device):
-        check(lib().egs_hseqr_batched(_ptr(h), nmat, n, _ptr(w), _ptr(info), _stream()), "egs_hseqr_batched")
+        queue = _workspace(h.device, 256)
+        check(lib().egs_hseqr_batched(_ptr(h), nmat, n, _ptr(w), _ptr(info), _ptr(queue), _stream()), "egs_hseqr_batched")
     return w, info
 
 

@@ -31,8 +31,8 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_workspace_queries_are_host_only(pkg):
     lib = pkg._capi.lib()
     c = pkg._capi
-    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 524288, 64) == 16384 * 64 * 64 * 8     # chunked Hessenberg scratch
-    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 10, 64) == 10 * 64 * 64 * 8
+    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 524288, 64) == 65536 * 64 * 64 * 8 + 256   # chunked Hessenberg scratch + queue
+    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 10, 64) == 10 * 64 * 64 * 8 + 256
     assert lib.egs_eig_workspace_bytes(c.EGS_C128, 768, 256) == 768 * 256 * 256 * 16     # workgroup path: full copy
     assert lib.egs_eig_workspace_bytes(c.EGS_C128, 768, 64) == 768 * 64 * 64 * 16       # Hessenberg hand-over
     assert lib.egs_eig_workspace_bytes(c.EGS_C128, 10, 96) == 256                        # workgroup LDS path: none
