@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""End-to-end wall clock of the drop-in ``eval_eig`` on the reference's MQAR configurations
+(configs/iclr2026/mqar/mqar-{lin,sm,norm}-attention.yaml shapes: L = 512, hidden 128, state_dim 128, 1 head, 2 layers,
+vocab 8192) with a 4096-sequence analysis batch: model construction, init pass (train mode), checkpoint load, trained
+pass -- block forwards through the HIP mixers, eta kernels --, histograms, report and the ten .npy artefacts.
+Synthetic tokens and a randomly initialised checkpoint (no dataset / trained weights offline)."""
+import copy, importlib, json, os, shutil, sys, tempfile, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("task-level-insights-from-eigenvalues-across-sequence-models_amd")
+
+
+def model_cfg(attention_fn):
+    cfg = dict(input_dim=1, output_dim=8192, layer="transformer", attention_fn=attention_fn, use_flash=False, num_layers=2,
+               hidden_dim=128, state_dim=128, num_heads=1, att_dropout=0.0, norm="layer", embedding=True, vocab_size=8192,
+               max_pos_embed=512, mixer="none", mixer_dim=128, dropout=0.1, classifier=False, pooling="mean", dual=False,
+               seq_len=512)
+    if attention_fn == "norm-attention":
+        cfg.update(mode="attention", norm_fn="softplus", approx_fn="elu", scale_B=True, offset=True, offset_init="uniform",
+                   learn_A=False, dim_conv=0)
+    return cfg
+
+
+def main():
+    B, L = int(os.environ.get("EGS_BENCH_B", 4096)), 512
+    rng = np.random.default_rng(1919)
+    X = torch.from_numpy(rng.integers(0, 8192, (B, L)))
+    for fn in ("lin-attention", "sm-attention", "norm-attention"):
+        cfg = model_cfg(fn)
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            os.mkdir("results")
+            torch.manual_seed(3)
+            torch.save(pkg.models.Transformer({k: v for k, v in cfg.items() if k != "layer"}).state_dict(), "ckpt.pth")
+            args = {"model": cfg, "train": {"lr": 0.01}, "dataset": {"name": "MQAR"}, "seed": 1919}
+            conf = {"batch_size": B, "save_path": os.path.join(tmp, "results") + "/"}
+            times = []
+            for rep in range(2):
+                shutil.rmtree("results")
+                os.mkdir("results")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = pkg.eval_eig(copy.deepcopy(args), conf, None, None, [(X, None, None)], "ckpt.pth", 0.99)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            nbytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk("results") for f in fs)
+            print(json.dumps({"attention_fn": fn, "batch": B, "seq_len": L, "layers": 2, "wall_s_first": times[0],
+                              "wall_s": times[1], "eig_shape": list(out[0].shape), "artefact_bytes": nbytes}), flush=True)
+            os.chdir(ROOT)
+
+
+if __name__ == "__main__":
+    main()
