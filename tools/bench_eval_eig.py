@@ -26,13 +26,17 @@ def main():
     B, L = int(os.environ.get("EGS_BENCH_B", 4096)), 512
     rng = np.random.default_rng(1919)
     X = torch.from_numpy(rng.integers(0, 8192, (B, L)))
-    for fn in ("lin-attention", "sm-attention", "norm-attention"):
-        cfg = model_cfg(fn)
+    mamba_cfg = dict(layer="mamba", version="mamba2", num_layers=2, num_heads=1, input_dim=1, output_dim=8192, hidden_dim=128,
+                     state_dim=128, conv_dim=4, expansion=1, dropout=0.0, glu=True, norm="layer", dual=False, prenorm=True,
+                     pooling="none", token_embedding=True, vocab_size=8192, seq_len=512)
+    for fn in ("lin-attention", "sm-attention", "norm-attention", "mamba2"):
+        cfg = dict(mamba_cfg) if fn == "mamba2" else model_cfg(fn)
         with tempfile.TemporaryDirectory() as tmp:
             os.chdir(tmp)
             os.mkdir("results")
             torch.manual_seed(3)
-            torch.save(pkg.models.Transformer({k: v for k, v in cfg.items() if k != "layer"}).state_dict(), "ckpt.pth")
+            cls = pkg.models.Mamba if fn == "mamba2" else pkg.models.Transformer
+            torch.save(cls({k: v for k, v in cfg.items() if k != "layer"}).state_dict(), "ckpt.pth")
             args = {"model": cfg, "train": {"lr": 0.01}, "dataset": {"name": "MQAR"}, "seed": 1919}
             conf = {"batch_size": B, "save_path": os.path.join(tmp, "results") + "/"}
             times = []
