@@ -221,6 +221,15 @@ size_t egs_softmax_eta_qk_workspace_bytes(int64_t batch, int64_t seqlen, int num
 int egs_softmax_eta_qk(const float* qk, int64_t batch, int64_t seqlen, int d_qk, int num_heads, double* eta,
                        void* workspace, size_t workspace_bytes, egs_stream_t stream);
 
+/* Depthwise causal conv1d + SiLU on channel-last activations: the conv blocks in front of the token mixers
+ * (models/attention.py:130-155, models/norm_attention.py:225-244, models/mamba.py:96-108, :130-134 --
+ * nn.Conv1d(groups = C, padding = K-1) truncated to L outputs, then nn.SiLU).
+ *   x : float[B, L, C] through (x_batch_stride, x_token_stride), channels contiguous
+ *   w : float[C, K] (= conv1d.weight[:, 0, :]), bias : float[C] or NULL, K <= 8;   y : float[B, L, C] contiguous */
+int egs_causal_conv1d_silu(const float* x, int64_t x_batch_stride, int64_t x_token_stride, const float* w,
+                           const float* bias, float* y, int64_t batch, int64_t seqlen, int channels, int kernel_size,
+                           egs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

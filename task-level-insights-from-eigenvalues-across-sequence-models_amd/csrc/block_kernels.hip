@@ -1424,4 +1424,73 @@ int softmax_attn_fwd_launch(const float* q, const float* k, int64_t qk_bs, int64
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Depthwise causal conv1d + SiLU over the channel-last activations (the conv blocks of MHA / MHNA / SSD:
+// models/attention.py:130-155, models/norm_attention.py:225-244, models/mamba.py:96-108, :130-134):
+//     y[b, t, c] = silu(bias[c] + sum_{j<K} w[c, j] x[b, t - (K-1) + j, c]),   x[t < 0] = 0
+// (nn.Conv1d(groups = C, padding = K-1) truncated to the first L outputs).  One pass over x: a thread owns 4
+// adjacent channels and a run of 16 tokens with the K-1 previous tokens as a register window.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kConvRun = 16, kConvMaxK = 8;
+
+__global__ __launch_bounds__(256) void causal_conv1d_silu_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_ts,
+                                                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int64_t seqlen, int channels, int kw) {
+    const int cq = blockIdx.x * blockDim.x + threadIdx.x;             // channel quad
+    const int c0 = cq * 4;
+    if (c0 >= channels) return;
+    const int64_t t0 = (int64_t)blockIdx.y * kConvRun;
+    const int64_t b = blockIdx.z;
+    const int nc = (channels - c0 < 4) ? channels - c0 : 4;
+    float wt[4][kConvMaxK], bs[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + (e < nc ? e : 0);
+        bs[e] = bias ? bias[c] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < kConvMaxK; ++j) wt[e][j] = (j < kw) ? w[c * kw + j] : 0.0f;
+    }
+    const float* xb = x + b * x_bs + c0;
+    float win[4][kConvMaxK];                                          // win[e][j] = x[t - (kw-1) + j] (valid j < kw)
+#pragma unroll
+    for (int j = 0; j < kConvMaxK; ++j) {
+        const int64_t t = t0 - (kw - 1) + j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = j < kw - 1 && t >= 0 && t < seqlen && e < nc;
+            const float v = xb[(ok ? t : 0) * x_ts + (e < nc ? e : 0)];
+            win[e][j] = ok ? v : 0.0f;
+        }
+    }
+    for (int u = 0; u < kConvRun; ++u) {
+        const int64_t t = t0 + u;
+        if (t >= seqlen) break;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xv = xb[t * x_ts + (e < nc ? e : 0)];
+            // slot kw-1 of the window takes the newest token (kw is runtime: a select chain over the 8 slots)
+#pragma unroll
+            for (int j = 0; j < kConvMaxK; ++j) win[e][j] = (j == kw - 1) ? xv : win[e][j];
+            float acc = bs[e];
+#pragma unroll
+            for (int j = 0; j < kConvMaxK; ++j) acc = fmaf(wt[e][j], win[e][j], acc);
+            if (e < nc) y[(b * seqlen + t) * channels + c0 + e] = acc / (1.0f + __expf(-acc));
+#pragma unroll
+            for (int j = 0; j + 1 < kConvMaxK; ++j) win[e][j] = win[e][j + 1];   // slide
+        }
+    }
+}
+
+int causal_conv1d_silu_launch(const float* x, int64_t x_bs, int64_t x_ts, const float* w, const float* bias, float* y,
+                              int64_t batch, int64_t seqlen, int channels, int kw, hipStream_t stream) {
+    if (batch == 0 || seqlen == 0) return 0;
+    const int quads = (channels + 3) / 4;
+    const int threads = quads < 256 ? ((quads + 63) / 64) * 64 : 256;
+    const dim3 grid((unsigned)((quads + threads - 1) / threads), (unsigned)((seqlen + kConvRun - 1) / kConvRun), (unsigned)batch);
+    hipLaunchKernelGGL(causal_conv1d_silu_kernel, grid, dim3(threads), 0, stream, x, x_bs, x_ts, w, bias, y, seqlen, channels,
+                       kw);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace egs

@@ -39,6 +39,8 @@ int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, con
 int threshold_hist_launch(const void*, int, int, int64_t, int64_t, int64_t, const double*, int, double*, hipStream_t);
 size_t linrec_workspace_bytes(int64_t, int64_t, int, int, int);
 int linrec_path(int, int, int, unsigned);
+int causal_conv1d_silu_launch(const float*, int64_t, int64_t, const float*, const float*, float*, int64_t, int64_t, int, int,
+                              hipStream_t);
 size_t softmax_eta_qk_workspace_bytes(int64_t, int64_t, int);
 int softmax_eta_qk_launch(const float*, int64_t, int64_t, int, int, double*, void*, size_t, hipStream_t);
 int softmax_attn_fwd_launch(const float*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, float*,
@@ -314,6 +316,21 @@ int egs_softmax_eta_qk(const float* qk, int64_t batch, int64_t seqlen, int d_qk,
     EGS_ARG(eta != nullptr, 6);
     EGS_ARG(workspace != nullptr, 7);
     return softmax_eta_qk_launch(qk, batch, seqlen, d_qk, num_heads, eta, workspace, workspace_bytes, as_stream(stream));
+}
+
+int egs_causal_conv1d_silu(const float* x, int64_t x_batch_stride, int64_t x_token_stride, const float* w,
+                           const float* bias, float* y, int64_t batch, int64_t seqlen, int channels, int kernel_size,
+                           egs_stream_t stream) {
+    EGS_ARG(batch >= 0 && batch <= 65535, 7);
+    EGS_ARG(seqlen >= 0 && (seqlen + 15) / 16 <= 65535, 8);
+    EGS_ARG(channels > 0, 9);
+    EGS_ARG(kernel_size >= 1 && kernel_size <= 8, 10);
+    if (batch == 0 || seqlen == 0) return 0;
+    EGS_ARG(x != nullptr, 1);
+    EGS_ARG(w != nullptr, 4);
+    EGS_ARG(y != nullptr, 6);
+    return causal_conv1d_silu_launch(x, x_batch_stride, x_token_stride, w, bias, y, batch, seqlen, channels, kernel_size,
+                                     as_stream(stream));
 }
 
 }  // extern "C"

@@ -266,8 +266,12 @@ FlashNormAttention = SelfNormAttention
 
 
 def _depthwise_causal(conv, act, x, seqlen):
-    """act(conv1d(x^T)[..., :L])^T with padding = kernel - 1 (models/attention.py:152-155)."""
-    return act(conv(x.transpose(1, 2))[..., :seqlen]).transpose(1, 2).contiguous()   # channels contiguous again
+    """act(conv1d(x^T)[..., :L])^T with padding = kernel - 1 (models/attention.py:152-155): one fused HIP pass over the
+    channel-last activations (``act`` is the module's nn.SiLU; kernels wider than 8 taps fall outside the ABI)."""
+    if conv.kernel_size[0] > 8:
+        raise NotImplementedError("depthwise conv kernels wider than 8 taps are not supported")
+    with torch.no_grad():
+        return ops.causal_conv1d_silu(x, conv.weight, conv.bias)
 
 
 class MHA(nn.Module):
@@ -505,7 +509,7 @@ class _SSDBase(nn.Module):
         xBC, dt = torch.split(self.in_proj(u), [self.d_inner + 2 * self.ngroups * self.d_state, n_dt], dim=-1)
         dt = F.softplus(dt + self.dt_bias)
         if self.use_conv:
-            xBC = self.act(self.conv1d(xBC.transpose(1, 2)).transpose(1, 2))[:, :seqlen, :].contiguous()
+            xBC = _depthwise_causal(self.conv1d, self.act, xBC, seqlen)
         gn = self.ngroups * self.d_state
         x, Bm, Cm = torch.split(xBC, [self.d_inner, gn, gn], dim=-1)
         return x, Bm, Cm, dt

@@ -356,3 +356,30 @@ def softmax_eta_from_qk(q, k):
         check(lib().egs_softmax_eta_qk(_ptr(qk), batch, seqlen, heads * hd, heads, _ptr(eta), _ptr(ws),
                                        ws.numel() * ws.element_size(), _stream()), "egs_softmax_eta_qk")
     return eta
+
+
+def causal_conv1d_silu(x, weight, bias=None):
+    """silu(depthwise causal conv1d) on channel-last activations: x [B, L, C] (contiguous channels), weight [C, 1, K] or
+    [C, K] (nn.Conv1d(groups=C).weight), bias [C] or None; K <= 8.  Returns [B, L, C] float32.
+    Replaces ``act(conv1d(x.transpose(1, 2))[..., :L]).transpose(1, 2)`` (models/attention.py:152-155 and twins)."""
+    _require_cuda(x, "x")
+    if x.dim() != 3:
+        raise ValueError(f"x must be [B, L, C], got {tuple(x.shape)}")
+    x = x if x.dtype == torch.float32 else x.float()
+    if x.shape[-1] > 1 and x.stride(-1) != 1:
+        x = x.contiguous()
+    batch, seqlen, channels = x.shape
+    w = weight.detach().reshape(weight.shape[0], -1).to(torch.float32).contiguous()
+    if w.shape[0] != channels:
+        raise ValueError(f"weight has {w.shape[0]} channels, x has {channels}")
+    kw = w.shape[1]
+    if kw > 8:
+        raise ValueError(f"kernel size {kw} exceeds the supported maximum of 8")
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    y = torch.empty((batch, seqlen, channels), dtype=torch.float32, device=x.device)
+    if batch == 0 or seqlen == 0:
+        return y
+    with torch.cuda.device(x.device):
+        check(lib().egs_causal_conv1d_silu(_ptr(x), x.stride(0), x.stride(1), _ptr(w), _ptr(b), _ptr(y), batch, seqlen,
+                                           channels, kw, _stream()), "egs_causal_conv1d_silu")
+    return y

@@ -373,3 +373,22 @@ def test_mixers_randomised_shapes(gpu_ops):
         y = gpu_ops.softmax_attention_fwd(dev(q), dev(k), dev(v))
         want_sm = BO.softmax_attention(np.stack([q, k], axis=2), v.reshape(B, L, H, cpg))
         close(y.reshape(B, L, H, cpg), want_sm, rtol=5e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cfg", [(2, 37, 5, 1), (3, 16, 64, 4), (1, 100, 130, 3), (2, 5, 8, 8), (4, 33, 257, 2)])
+def test_causal_conv1d_silu_vs_torch(gpu_ops, cfg):
+    """The fused depthwise causal conv + SiLU against the reference's formulation
+    act(conv1d(x^T, padding = K-1)[..., :L])^T (models/attention.py:152-155), also on a strided view."""
+    B, L, C, K = cfg
+    torch.manual_seed(sum(cfg))
+    conv = torch.nn.Conv1d(C, C, kernel_size=K, groups=C, padding=K - 1, bias=True).cuda()
+    wide = torch.randn(B, L, C + 7, device="cuda")
+    x = wide[..., 3: 3 + C]                                          # channel-contiguous view with a larger token stride
+    with torch.no_grad():
+        want = torch.nn.functional.silu(conv(x.transpose(1, 2))[..., :L]).transpose(1, 2)
+        got = gpu_ops.causal_conv1d_silu(x, conv.weight, conv.bias)
+        nobias = gpu_ops.causal_conv1d_silu(x, conv.weight.reshape(C, K), None)
+        want_nb = torch.nn.functional.silu(torch.nn.functional.conv1d(x.transpose(1, 2), conv.weight, None, padding=K - 1,
+                                                                      groups=C)[..., :L]).transpose(1, 2)
+    close(got, want.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    close(nobias, want_nb.cpu().numpy(), rtol=2e-6, atol=1e-6)
