@@ -15,9 +15,9 @@ Modules are created in the reference's order with the reference's initialisers, 
 followed by construction draws the same parameters (the "init" spectra of eval_eig, quirk Q8).
 
 Forward only (the analysis never back-propagates): the token mixers run in the HIP library through the C ABI
-(``egs_linear_recurrence_fwd``, ``egs_softmax_attention_fwd``, ``egs_mamba2_lambda``); dense layers, LayerNorm,
-embeddings, the depthwise conv and dropout are torch ops on the GPU (rocBLAS / MIOpen plumbing).  There is no CPU path:
-a forward on CPU tensors raises.
+(``egs_linear_recurrence_fwd``, ``egs_softmax_attention_fwd``, ``egs_causal_conv1d_silu``); dense layers, LayerNorm,
+embeddings and dropout are torch ops on the GPU (rocBLAS plumbing).  There is no CPU path: a forward on CPU tensors
+raises.
 """
 import math
 
