@@ -285,3 +285,26 @@ def test_orbax_chunked_arrays_and_placeholders(pkg, tmp_path):
         pkg.ckpt.read_aggregate(str(tmp_path / "c2"))
     with pytest.raises(FileNotFoundError):
         pkg.ckpt.read_aggregate(str(tmp_path / "nothing_here"))
+
+
+def test_dropin_models_have_reference_parameter_names_and_no_cpu_path(pkg, golden):
+    """CPU-side check of the drop-in models: state_dict keys equal the reference's (recorded in the goldens), and a
+    forward on CPU tensors raises instead of falling back."""
+    import json
+    g = golden("blocks")
+    for name in ("lin_conv_gate", "sm", "norm_exp"):
+        cfg = json.loads(bytes(g[f"{name}/cfg"]).decode())
+        keys = json.loads(bytes(g[f"{name}/keys"]).decode())
+        model = pkg.models.Transformer(dict(cfg))
+        assert list(model.state_dict().keys()) == keys
+        model.load_state_dict({k: torch.from_numpy(g[f"{name}/sd/{k}"]) for k in keys})
+    x = torch.from_numpy(g["norm_exp/x"])
+    with pytest.raises(pkg._capi.EigspecError, match="no CPU fallback"):
+        model.eval()(x)
+    mamba = pkg.models.Mamba(dict(version="mamba2", num_layers=1, input_dim=3, output_dim=2, hidden_dim=32, num_heads=1,
+                                  state_dim=8, conv_dim=4, expansion=1, dropout=0.0, glu=False, norm="layer", prenorm=True,
+                                  dual=False, pooling="none", token_embedding=False))
+    assert {"blocks.0.mamba.in_proj.weight", "blocks.0.mamba.A_log", "blocks.0.mamba.dt_bias", "blocks.0.mamba.D",
+            "blocks.0.mamba.conv1d.weight", "blocks.0.mamba.out_proj.weight"} <= set(mamba.state_dict())
+    with pytest.raises(pkg._capi.EigspecError, match="no CPU fallback"):
+        mamba.eval()(torch.zeros(1, 5, 3))
