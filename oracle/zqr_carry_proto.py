@@ -1,5 +1,6 @@
-"""Prototype (NumPy, test infrastructure only) of the REGISTER-CARRIED single-shift QR sweep planned for the
-workgroup-per-matrix complex solver (n >= 128) -- DESIGN.md section 4, "what large batches want next".
+"""Prototype (NumPy, test infrastructure only) of the REGISTER-CARRIED single-shift QR sweep for the
+workgroup-per-matrix complex solver (n >= 128) -- DESIGN.md section 4.  (The HIP version built from it was correct but
+slower than the plain sweep and was not adopted; the prototype stays as the executable description of the data flow.)
 
 The kernel of this round (csrc/eig_cplx.hip, phase 2) reads and writes two rows and two columns of the active window
 in global memory at every bulge step, i.e. every row is moved twice (as the lower row of step k-1 and the upper row of
