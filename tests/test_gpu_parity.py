@@ -625,3 +625,22 @@ def test_softmax_eta_matrix_core_and_valu_kernels(gpu_ops, monkeypatch, cfg):
     assert np.abs(got - want).max() <= 2e-5 * scale
     assert np.abs(valu - want).max() <= 2e-5 * scale
     assert np.abs(got - valu).max() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("n,nmat", [(64, 6000), (40, 9001), (17, 20000)])
+def test_eig_real_work_queue_covers_every_matrix(gpu_ops, n, nmat):
+    """Batches larger than one resident wave set run through the QR kernel's work queue: every matrix must be solved
+    exactly once -- checked for ALL matrices through the trace (sum of eigenvalues) and the squared Frobenius-type
+    invariant sum(lambda^2) = trace(A^2), and against LAPACK on a sample."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n * 1000 + 7)
+    a = torch.randn((nmat, n, n), generator=g, device="cuda", dtype=torch.float64) / np.sqrt(n)
+    w, info = gpu_ops.eig_general_batched(a)
+    assert int(info.abs().sum()) == 0
+    tr = torch.diagonal(a, dim1=1, dim2=2).sum(dim=1)
+    tr2 = torch.einsum("bij,bji->b", a, a)
+    assert float((w.sum(dim=1).real - tr).abs().max()) < 1e-10
+    assert float((w.sum(dim=1).imag).abs().max()) < 1e-10
+    assert float(((w * w).sum(dim=1).real - tr2).abs().max()) < 1e-9
+    idx = torch.tensor([0, 1, nmat // 2, nmat - 2, nmat - 1], device="cuda")
+    assert O.max_abs_dlambda(w[idx].cpu().numpy(), O.eigvals_dense(a[idx].cpu().numpy())) < 1e-9
