@@ -230,6 +230,12 @@ int egs_causal_conv1d_silu(const float* x, int64_t x_batch_stride, int64_t x_tok
                            const float* bias, float* y, int64_t batch, int64_t seqlen, int channels, int kernel_size,
                            egs_stream_t stream);
 
+/* LayerNorm over the last dimension, fp32, biased variance (nn.LayerNorm of the blocks: models/transformer.py:84-86,
+ * :143-144, models/mamba.py:312-313).  x : float[rows, d] through x_row_stride (d <= 1024); gamma, beta : float[d] or
+ * NULL; y : float[rows, d] contiguous. */
+int egs_layer_norm(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, float* y, int64_t rows,
+                   int d, float eps, egs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1493,4 +1493,58 @@ int causal_conv1d_silu_launch(const float* x, int64_t x_bs, int64_t x_ts, const 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension (nn.LayerNorm(hidden_dim) of TransformerBlock / MambaBlock / Transformer,
+// models/transformer.py:84-86, :143-144, models/mamba.py:312-313): y = (x - mean) / sqrt(var + eps) * gamma + beta with
+// the biased variance, fp32.  One wavefront per row, the row in registers (up to 16 floats per lane), mean and variance
+// as two in-register passes -- one read and one write of the activations (the library kernel it replaces took 2.2 ms
+// for 2.1 M rows of 128, against 0.45 ms of pure traffic).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLnMaxPerLane = 16;                                      // rows up to 1024 wide
+
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, int64_t x_rs,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ y, int64_t rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * x_rs;
+    float v[kLnMaxPerLane];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int c = lane + 64 * i;
+        const float t = xr[c < d ? c : d - 1];
+        v[i] = c < d ? t : 0.0f;
+        sum += v[i];
+        if (64 * (i + 1) >= d) break;                                  // block-uniform
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int c = lane + 64 * i;
+        const float dlt = c < d ? v[i] - mean : 0.0f;
+        sq = fmaf(dlt, dlt, sq);
+        if (64 * (i + 1) >= d) break;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + eps);
+    float* yr = y + row * (int64_t)d;
+#pragma unroll
+    for (int i = 0; i < kLnMaxPerLane; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d) yr[c] = fmaf((v[i] - mean) * rstd, gamma ? gamma[c] : 1.0f, beta ? beta[c] : 0.0f);
+        if (64 * (i + 1) >= d) break;
+    }
+}
+
+int layer_norm_launch(const float* x, int64_t x_rs, const float* gamma, const float* beta, float* y, int64_t rows, int d,
+                      float eps, hipStream_t stream) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, x_rs, gamma, beta, y, rows,
+                       d, eps);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace egs

@@ -39,6 +39,7 @@ int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, con
 int threshold_hist_launch(const void*, int, int, int64_t, int64_t, int64_t, const double*, int, double*, hipStream_t);
 size_t linrec_workspace_bytes(int64_t, int64_t, int, int, int);
 int linrec_path(int, int, int, unsigned);
+int layer_norm_launch(const float*, int64_t, const float*, const float*, float*, int64_t, int, float, hipStream_t);
 int causal_conv1d_silu_launch(const float*, int64_t, int64_t, const float*, const float*, float*, int64_t, int64_t, int, int,
                               hipStream_t);
 size_t softmax_eta_qk_workspace_bytes(int64_t, int64_t, int);
@@ -331,6 +332,17 @@ int egs_causal_conv1d_silu(const float* x, int64_t x_batch_stride, int64_t x_tok
     EGS_ARG(y != nullptr, 6);
     return causal_conv1d_silu_launch(x, x_batch_stride, x_token_stride, w, bias, y, batch, seqlen, channels, kernel_size,
                                      as_stream(stream));
+}
+
+int egs_layer_norm(const float* x, int64_t x_row_stride, const float* gamma, const float* beta, float* y, int64_t rows,
+                   int d, float eps, egs_stream_t stream) {
+    EGS_ARG(rows >= 0 && (rows + 3) / 4 <= 2147483647LL, 6);
+    EGS_ARG(d > 0 && d <= 1024, 7);
+    EGS_ARG(x_row_stride >= d, 2);
+    if (rows == 0) return 0;
+    EGS_ARG(x != nullptr, 1);
+    EGS_ARG(y != nullptr, 5);
+    return layer_norm_launch(x, x_row_stride, gamma, beta, y, rows, d, eps, as_stream(stream));
 }
 
 }  // extern "C"

@@ -15,8 +15,8 @@ Modules are created in the reference's order with the reference's initialisers, 
 followed by construction draws the same parameters (the "init" spectra of eval_eig, quirk Q8).
 
 Forward only (the analysis never back-propagates): the token mixers run in the HIP library through the C ABI
-(``egs_linear_recurrence_fwd``, ``egs_softmax_attention_fwd``, ``egs_causal_conv1d_silu``); dense layers, LayerNorm,
-embeddings and dropout are torch ops on the GPU (rocBLAS plumbing).  There is no CPU path: a forward on CPU tensors
+(``egs_linear_recurrence_fwd``, ``egs_softmax_attention_fwd``, ``egs_causal_conv1d_silu``, ``egs_layer_norm``); dense
+layers, embeddings and dropout are torch ops on the GPU (rocBLAS plumbing).  There is no CPU path: a forward on CPU tensors
 raises.
 """
 import math
@@ -158,6 +158,16 @@ class TokenEmbeddings(nn.Module):
                 position_ids = torch.arange(seqlen, dtype=torch.long, device=input_ids.device)
             emb = emb + self.position_embeddings(position_ids)
         return emb
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm with the same parameters (weight, bias) whose forward is one HIP pass (egs_layer_norm)."""
+
+    def forward(self, x):
+        if len(self.normalized_shape) != 1 or self.normalized_shape[0] > 1024:
+            return super().forward(x)
+        with torch.no_grad():
+            return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -410,7 +420,7 @@ class TransformerBlock(nn.Module):
             raise RuntimeError("{0} mixer not implemented yet!".format(mixer))
         if norm != "layer":
             raise RuntimeError("{0} norm not implemented yet!".format(norm))
-        self.norm = nn.LayerNorm(hidden_dim)
+        self.norm = LayerNorm(hidden_dim)
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
@@ -443,7 +453,7 @@ class Transformer(nn.Module):
             self.match = MATCH(cfg["output_dim"] * 2, cfg["mixer_dim"], cfg["output_dim"])
         if cfg["norm"] != "layer":
             raise RuntimeError("{0} norm not implemented yet!".format(cfg["norm"]))
-        self.norm = nn.LayerNorm(hidden_dim)
+        self.norm = LayerNorm(hidden_dim)
         self.dropout = nn.Dropout(cfg["dropout"])
 
     def forward(self, x):
@@ -588,7 +598,7 @@ class MambaBlock(nn.Module):
         self.activation = nn.GELU()
         self.dropout = nn.Dropout(dropout)
         if norm == "layer":
-            self.norm = nn.LayerNorm(hidden_dim)
+            self.norm = LayerNorm(hidden_dim)
         elif norm == "batch":
             raise RuntimeError("dimensions don't agree for batch norm to work")
         self.prenorm = prenorm

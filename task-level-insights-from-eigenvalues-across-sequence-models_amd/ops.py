@@ -289,6 +289,11 @@ def linear_recurrence_fwd(q, k, v, decay=None, vscale=None, w=None, skip=None, p
     if batch == 0 or seqlen == 0:
         return y
     aligned = (q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0 and all(st % 4 == 0 for st in q.stride()[:3]))
+    if not aligned and d_state % 4 == 0 and d_state <= 128:
+        # e.g. slices of a projection whose width is not a multiple of 4 (Wvqkn: D + 2 d_qk + H): one copy buys the
+        # matrix-core kernels, which need 16-byte aligned q / k rows
+        q, k = q.contiguous(), k.contiguous()
+        aligned = True
     flags = ((1 if decay is not None else 0) | (2 if (w is not None and not normalise) else 0) |
              (4 if skip is not None else 0) | (8 if phi else 0) | (16 if normalise else 0) |
              (32 if float(k_scale) != 1.0 else 0) | (64 if aligned else 0))             # EGS_REC_* of eigspec.h
@@ -383,3 +388,26 @@ def causal_conv1d_silu(x, weight, bias=None):
         check(lib().egs_causal_conv1d_silu(_ptr(x), x.stride(0), x.stride(1), _ptr(w), _ptr(b), _ptr(y), batch, seqlen,
                                            channels, kw, _stream()), "egs_causal_conv1d_silu")
     return y
+
+
+def layer_norm(x, weight=None, bias=None, eps=1e-5):
+    """LayerNorm over the last dimension (fp32, biased variance), x [..., d] with a contiguous last dim and d <= 1024.
+    Replaces nn.LayerNorm.forward in the blocks (models/transformer.py:93-99, models/mamba.py:318-328)."""
+    _require_cuda(x, "x")
+    x = x if x.dtype == torch.float32 else x.float()
+    d = x.shape[-1]
+    if d > 1024:
+        raise ValueError(f"layer_norm supports a normalised dimension up to 1024, got {d}")
+    x2 = x.reshape(-1, d)
+    if x2.shape[0] > 0 and x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    y = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+    if rows == 0:
+        return y.reshape(x.shape)
+    g = None if weight is None else weight.detach().to(torch.float32).contiguous()
+    b = None if bias is None else bias.detach().to(torch.float32).contiguous()
+    with torch.cuda.device(x.device):
+        check(lib().egs_layer_norm(_ptr(x2), x2.stride(0), _ptr(g), _ptr(b), _ptr(y), rows, d, float(eps), _stream()),
+              "egs_layer_norm")
+    return y.reshape(x.shape)

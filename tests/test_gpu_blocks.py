@@ -392,3 +392,24 @@ def test_causal_conv1d_silu_vs_torch(gpu_ops, cfg):
                                                                       groups=C)[..., :L]).transpose(1, 2)
     close(got, want.cpu().numpy(), rtol=2e-6, atol=1e-6)
     close(nobias, want_nb.cpu().numpy(), rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(7, 128), (3, 5, 32), (2, 3, 4, 200), (1000, 1), (5, 1024), (33, 130)])
+def test_layer_norm_vs_torch(gpu_ops, shape):
+    torch.manual_seed(sum(shape))
+    d = shape[-1]
+    x = torch.randn(*shape, device="cuda") * 3 + 1
+    ln = torch.nn.LayerNorm(d).cuda()
+    with torch.no_grad():
+        ln.weight.normal_()
+        ln.bias.normal_()
+        want = ln(x)
+        got = gpu_ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+        plain = gpu_ops.layer_norm(x)
+        want_plain = torch.nn.functional.layer_norm(x, (d,))
+        wide = torch.randn(6, d + 3, device="cuda")
+        strided = gpu_ops.layer_norm(wide[:, :d], ln.weight, ln.bias)
+        want_strided = ln(wide[:, :d])
+    close(got, want.cpu().numpy(), rtol=3e-6, atol=2e-6)
+    close(plain, want_plain.cpu().numpy(), rtol=3e-6, atol=2e-6)
+    close(strided, want_strided.cpu().numpy(), rtol=3e-6, atol=2e-6)
