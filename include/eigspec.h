@@ -80,18 +80,30 @@ int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const do
  * Replaces np.linalg.eigvals (LAPACK ?geev, analysis/eval_eig.py:296), generalised from one matrix per
  * layer to a batch.  Householder reduction to Hessenberg form + shifted QR (Francis double-shift for real
  * input, single-shift for complex input), eigenvalues only.
- *   a      : [nmat] matrices, element (i,j) of matrix m at a[m*stride + i*lda + j] (elements of `dtype`,
- *            EGS_F64 or EGS_C128; row-major).  Not modified.
+ *   a      : [nmat] matrices, element (i,j) of matrix m at a[m*stride + i*lda + j] (elements of `dtype`;
+ *            row-major).  Not modified.
  *   w      : complex128[nmat, n] eigenvalues, in the order the deflation produced them (sort to compare).
  *   info   : int32[nmat]; 0 = converged, k > 0 = QR failed to deflate with k eigenvalues outstanding
  *            (their slots hold NaN), as LAPACK's xHSEQR info.
  *   workspace : device scratch of egs_eig_workspace_bytes(dtype, nmat, n) bytes, 256-byte aligned.
- * n <= 64 real and n <= 64 complex run LDS-resident (one wavefront per matrix); larger n (<= 1024) run
- * one workgroup per matrix out of the workspace copy. */
+ * n <= 64 real and n <= 64 complex run LDS-resident (one wavefront per matrix); 64 < n <= 96 one workgroup per
+ * matrix out of an LDS copy; larger n (<= 1024; the reference's S4 state_dim 128 / 512 and config C5's 256) run the
+ * level-3 path: blocked Householder reduction with fp64 matrix-core panel updates, then small-bulge multishift QR
+ * (one workgroup of 16 wavefronts per matrix, working copy in the workspace).
+ * dtype EGS_F32 / EGS_C64 inputs are widened on load and solved in double precision (w stays complex128). */
 size_t egs_eig_workspace_bytes(int dtype, int64_t nmat, int n);
 int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int lda, int64_t stride,
                             double* w, int32_t* info, void* workspace, size_t workspace_bytes,
                             egs_stream_t stream);
+
+/* The two stages of the level-3 path (n > 64 .. 1024), exposed separately like LAPACK's xGEHRD / xHSEQR.
+ *   egs_hessenberg_general_batched : a (dtype as above, row-major, not modified) -> h, complex128[nmat, n, n]: the
+ *       upper-Hessenberg reduction of the TRANSPOSE of each (balanced) matrix, stored column-major -- i.e. read as a
+ *       row-major [n, n] array, h is LOWER Hessenberg and has the eigenvalues of a.  info[m] = n flags NaN / Inf input.
+ *   egs_hseqr_general_batched      : h as produced above (destroyed) -> w complex128[nmat, n], info. */
+int egs_hessenberg_general_batched(const void* a, int dtype, int64_t nmat, int n, int lda, int64_t stride, double* h,
+                                   double* w, int32_t* info, egs_stream_t stream);
+int egs_hseqr_general_batched(double* h, int64_t nmat, int n, double* w, int32_t* info, egs_stream_t stream);
 
 /* The two stages of the real LDS-resident solver (dtype EGS_F64, n <= 64), exposed separately like LAPACK's
  * xGEHRD / xHSEQR so that callers (and bench.py) can time or reuse them individually.

@@ -55,6 +55,24 @@ int hess_real_launch(const double*, int64_t, int, int, int64_t, double*, int32_t
 int hqr_real_launch(const double*, int64_t, int, double*, int32_t*, int, hipStream_t, unsigned long long*);
 size_t eig_cplx_workspace_bytes(int64_t, int);
 int eig_cplx_launch(const void*, bool, int64_t, int, int, int64_t, double*, int32_t*, void*, size_t, hipStream_t);
+size_t eig_zlarge_workspace_bytes(int64_t, int);
+int zhess_blocked_launch(const void*, bool, int64_t, int, int, int64_t, double*, int32_t*, void*, hipStream_t);
+int zmsqr_launch(int64_t, int, double*, int32_t*, void*, hipStream_t);
+
+// float / complex64 -> double / complex128, packed [nmat, n, n] (the single-precision entry of the dense solver)
+__global__ void widen_f32_kernel(const float* __restrict__ src, double* __restrict__ dst, int64_t nmat, int n, int lda,
+                                 int64_t stride, int comps) {
+    const int64_t per = (int64_t)n * n * comps;
+    const int64_t total = nmat * per;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = idx / per, e = idx - m * per;
+        const int64_t el = e / comps, cpt = e - el * comps;
+        const int64_t i = el / n, j = el - i * n;
+        dst[idx] = (double)src[(m * stride + i * lda + j) * comps + cpt];
+    }
+}
+
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace egs
 
@@ -106,17 +124,48 @@ int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const do
     return s4_dplr_launch(lambda_re, lambda_im, p_re, p_im, log_step, nmat, n, ab, as_stream(stream));
 }
 
-size_t egs_eig_workspace_bytes(int dtype, int64_t nmat, int n) {
-    if (nmat <= 0 || n <= 0) return 256;
+static size_t eig_core_workspace_bytes(bool real, int64_t nmat, int n) {
     size_t b;
-    if (dtype == EGS_F64 && n <= 64) b = eig_real_lds_workspace_bytes(nmat, n);
+    if (real && n <= 64) b = eig_real_lds_workspace_bytes(nmat, n);
     else b = eig_cplx_workspace_bytes(nmat, n);
     return b < 256 ? 256 : b;
 }
 
+size_t egs_eig_workspace_bytes(int dtype, int64_t nmat, int n) {
+    if (nmat <= 0 || n <= 0) return 256;
+    const bool real = dtype == EGS_F64 || dtype == EGS_F32;
+    size_t b = eig_core_workspace_bytes(real, nmat, n);
+    if (dtype == EGS_F32 || dtype == EGS_C64) b = align256(b) + (size_t)nmat * n * n * (real ? 8 : 16);
+    return b;
+}
+
+// widens single-precision input into the tail of the workspace; on return *a / *lda / *stride describe the fp64 copy
+static int widen_if_single(const void** a, int dtype, int64_t nmat, int n, int* lda, int64_t* stride, void* workspace,
+                           size_t workspace_bytes, hipStream_t stream) {
+    if (dtype != EGS_F32 && dtype != EGS_C64) return 0;
+    const bool real = dtype == EGS_F32;
+    const size_t core = align256(eig_core_workspace_bytes(real, nmat, n));
+    const size_t need = core + (size_t)nmat * n * n * (real ? 8 : 16);
+    if (workspace_bytes < need) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, need);
+        return -9;
+    }
+    double* dst = reinterpret_cast<double*>(static_cast<char*>(workspace) + core);
+    const int64_t total = nmat * (int64_t)n * n * (real ? 1 : 2);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(widen_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<const float*>(*a), dst,
+                       nmat, n, *lda, *stride, real ? 1 : 2);
+    EGS_LAUNCH_CHECK();
+    *a = dst;
+    *lda = n;
+    *stride = (int64_t)n * n;
+    return 0;
+}
+
 int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int lda, int64_t stride, double* w,
                             int32_t* info, void* workspace, size_t workspace_bytes, egs_stream_t stream) {
-    EGS_ARG(dtype == EGS_F64 || dtype == EGS_C128, 2);
+    EGS_ARG(dtype >= EGS_F32 && dtype <= EGS_C128, 2);
     EGS_ARG(nmat >= 0, 3);
     EGS_ARG(n >= 0 && n <= 1024, 4);
     if (nmat == 0 || n == 0) return 0;
@@ -126,11 +175,38 @@ int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int l
     EGS_ARG(w != nullptr, 7);
     EGS_ARG(info != nullptr, 8);
     EGS_ARG(workspace != nullptr, 9);
-    if (dtype == EGS_F64 && n <= 64)
+    const bool real = dtype == EGS_F64 || dtype == EGS_F32;
+    const int st = widen_if_single(&a, dtype, nmat, n, &lda, &stride, workspace, workspace_bytes, as_stream(stream));
+    if (st) return st;
+    if (real && n <= 64)
         return eig_real_lds_launch(static_cast<const double*>(a), nmat, n, lda, stride, w, info, workspace,
                                    workspace_bytes, as_stream(stream));
-    return eig_cplx_launch(a, dtype == EGS_F64, nmat, n, lda, stride, w, info, workspace, workspace_bytes,
-                           as_stream(stream));
+    return eig_cplx_launch(a, real, nmat, n, lda, stride, w, info, workspace, workspace_bytes, as_stream(stream));
+}
+
+int egs_hessenberg_general_batched(const void* a, int dtype, int64_t nmat, int n, int lda, int64_t stride, double* h,
+                                   double* w, int32_t* info, egs_stream_t stream) {
+    EGS_ARG(dtype == EGS_F64 || dtype == EGS_C128, 2);
+    EGS_ARG(nmat >= 0, 3);
+    EGS_ARG(n > 64 && n <= 1024, 4);
+    if (nmat == 0) return 0;
+    EGS_ARG(a != nullptr, 1);
+    EGS_ARG(lda >= n, 5);
+    EGS_ARG(stride >= (int64_t)(n - 1) * lda + n || nmat == 1, 6);
+    EGS_ARG(h != nullptr, 7);
+    EGS_ARG(w != nullptr, 8);
+    EGS_ARG(info != nullptr, 9);
+    return zhess_blocked_launch(a, dtype == EGS_F64, nmat, n, lda, stride, w, info, h, as_stream(stream));
+}
+
+int egs_hseqr_general_batched(double* h, int64_t nmat, int n, double* w, int32_t* info, egs_stream_t stream) {
+    EGS_ARG(nmat >= 0, 2);
+    EGS_ARG(n > 64 && n <= 1024, 3);
+    if (nmat == 0) return 0;
+    EGS_ARG(h != nullptr, 1);
+    EGS_ARG(w != nullptr, 4);
+    EGS_ARG(info != nullptr, 5);
+    return zmsqr_launch(nmat, n, w, info, h, as_stream(stream));
 }
 
 int egs_hessenberg_batched(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h,

@@ -476,9 +476,15 @@ size_t eig_cplx_workspace_bytes(int64_t nmat, int n) {
     return (size_t)nmat * n * n * 2 * sizeof(double);
 }
 
+int eig_zlarge_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, int64_t stride, double* w,
+                      int32_t* info, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, int64_t stride, double* w,
                     int32_t* info, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (nmat == 0 || n == 0) return 0;
+    // n > 96: level-3 path (eig_zlarge.hip); EGS_ZLARGE_OFF keeps the unblocked workgroup kernel below (A/B runs)
+    if (n > kCplxLdsMaxN && n <= 1024 && !getenv("EGS_ZLARGE_OFF"))
+        return eig_zlarge_launch(a, in_real, nmat, n, lda, stride, w, info, workspace, workspace_bytes, stream);
     if (n > 1024) {
         set_error("n = %d exceeds the supported maximum of 1024", n);
         return -4;

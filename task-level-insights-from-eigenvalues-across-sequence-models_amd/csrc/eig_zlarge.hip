@@ -1,0 +1,851 @@
+// K5 (complex, n > 96): batched eigenvalues of dense complex128 matrices by LEVEL-3 algorithms, one workgroup of
+// 16 wavefronts per matrix.
+//
+// Replaces np.linalg.eigvals(Ab) on the bilinear-discretised S4 DPLR matrix (analysis/eval_eig.py:296) at the orders
+// the reference's configs use above the LDS-resident kernels: state_dim 128 (configs/iclr2026/mqar/mqar-s4.yaml:33),
+// 512 (configs/iclr2026/wikitext/wikitext-103-s4.yaml:34), and BASELINE config C5 (n = 256).
+//
+//   zhess_blocked_kernel : blocked Householder reduction to Hessenberg form (the published xGEHRD / xLAHR2 scheme).
+//       Per panel of NB columns: one matrix-vector product with the trailing matrix per column (the only
+//       level-2 part: coalesced 16-byte loads, partial sums over column groups), V / Y / T kept in LDS; then the
+//       level-3 updates on v_mfma_f64_16x16x4_f64: Y_top = A V T, A <- A - Y V^H, A <- (I - V T^H V^H) A with the
+//       trailing tiles held in accumulator registers between the right and the left update (one read + one write of
+//       the trailing matrix per panel).  A complex product is four real MFMAs.
+//   zmsqr_kernel         : small-bulge multishift QR (Braman / Byers / Mathias, no aggressive early deflation).
+//       Chains of 16 single-shift bulges two rows apart are chased through 64 x 64 diagonal windows held in LDS
+//       (wave = bulge; lane = column in the row phase, lane = row in the column phase), the reflectors accumulated
+//       into U; rows above / columns right of the window are then updated by U as 64 x 64 x 64 complex products on
+//       the fp64 matrix cores.  Shifts: eigenvalues of the trailing 8 x 8 block (each used twice), computed by the
+//       wave-per-matrix single-shift iteration of zq_common.h, which also finishes deflated blocks of order <= 16.
+//
+// The working copy is the TRANSPOSE of the caller's row-major matrix (same bytes read as column-major; the spectrum
+// of A^T is that of A), which makes every streamed access of the reduction contiguous.
+// oracle/zms_proto.py restates both kernels step for step in NumPy (test infrastructure).
+#include <stdlib.h>
+
+#include "zq_common.h"
+
+namespace egs {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4d mfma64(double a, double b, v4d c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+constexpr int kZL = 1024;      // threads per workgroup (16 wavefronts)
+constexpr int kZLW = kZL / 64;
+
+__host__ __device__ inline int zl_np(int n) { return (n + 15) & ~15; }
+
+// LDS-safe accumulation of a double (ds_add_f64)
+__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// ---------------------------------------------------------------------------------------------------
+// blocked Hessenberg reduction
+// ---------------------------------------------------------------------------------------------------
+template <int NB, int TPW>
+__global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __restrict__ a, int in_real, int n, int lda,
+                                                            int64_t stride, double* __restrict__ w,
+                                                            int32_t* __restrict__ info_out, double* __restrict__ work,
+                                                            int balance) {
+    extern __shared__ double dynl[];
+    __shared__ double red[kZLW];
+    __shared__ zq s_alpha;
+    __shared__ int s_idx;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t mat = blockIdx.x;
+    const int np = zl_np(n);
+    const int ldv = np + 1;
+    zq* Vs = reinterpret_cast<zq*>(dynl);        // [NB][ldv]   V(r, jj) at Vs[jj * ldv + r]
+    zq* Ys = Vs + NB * ldv;                      // [NB][ldv]
+    zq* Tsh = Ys + NB * ldv;                     // [NB][NB]    upper triangular
+    zq* scr = Tsh + NB * NB;                     // [kZL]       b vector / matvec partials / W and X of the left update
+    zq* wsh = scr + kZL;                         // [NB]
+    zq* w2sh = wsh + NB;                         // [NB]
+    zq* zsh = w2sh + NB;                         // [NB]
+    zq* M = reinterpret_cast<zq*>(work) + mat * (int64_t)n * n;
+#define MM(i, j) M[(int64_t)(j) * n + (i)]
+
+    // ---- load (transposed view: M(i,j) = A(j,i)) ----
+    if (tid == 0) s_idx = 0;
+    __syncthreads();
+    {
+        const double* src = a + mat * stride * (in_real ? 1 : 2);
+        bool bad = false;
+        for (int idx = tid; idx < n * n; idx += kZL) {
+            const int j = idx / n, i = idx - j * n;          // M(i,j) = A(j,i) = src[j*lda + i]
+            zq v;
+            if (in_real) v = {src[(int64_t)j * lda + i], 0.0};
+            else v = {src[2 * ((int64_t)j * lda + i)], src[2 * ((int64_t)j * lda + i) + 1]};
+            M[idx] = v;
+            if (!(fabs(v.re) <= 1.7976931348623157e308) || !(fabs(v.im) <= 1.7976931348623157e308)) bad = true;
+        }
+        if (bad) s_idx = 1;
+    }
+    __syncthreads();
+    if (s_idx != 0) {                    // NaN / Inf input: an error like numpy.linalg.eigvals, not a spectrum
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        double* wbad = w + mat * 2 * (int64_t)n;
+        for (int j = tid; j < 2 * n; j += kZL) wbad[j] = qnan;
+        if (tid == 0) info_out[mat] = n;
+        return;
+    }
+    if (tid == 0) info_out[mat] = 0;
+
+    // ---- xGEBAL: permutation to isolate eigenvalues + power-of-two equilibration (what xGEEV does first) ----
+    if (balance) {
+        double* cn = reinterpret_cast<double*>(Ys);
+        double* rn = cn + n;
+        double* fs = rn + n;
+        int* cnt = reinterpret_cast<int*>(fs + n);
+#define ZNZ(i, j) (MM(i, j).re != 0.0 || MM(i, j).im != 0.0)
+#define ZSWAP(x, y)        \
+    {                      \
+        const zq t_ = (x); \
+        (x) = (y);         \
+        (y) = t_;          \
+    }
+        int k0 = 0, l0 = n - 1;
+        for (int i = tid; i < n; i += kZL) {                          // off-diagonal nonzeros of row i
+            int c = 0;
+            for (int j = 0; j < n; ++j) c += (j != i && ZNZ(i, j)) ? 1 : 0;
+            cnt[i] = c;
+        }
+        __syncthreads();
+        while (l0 > 0) {
+            if (tid == 0) s_idx = -1;
+            __syncthreads();
+            for (int i = tid; i <= l0; i += kZL)
+                if (cnt[i] == 0) atomicMax(&s_idx, i);
+            __syncthreads();
+            const int r = s_idx;
+            __syncthreads();
+            if (r < 0) break;
+            if (r != l0) {
+                for (int t = tid; t <= l0; t += kZL) ZSWAP(MM(t, r), MM(t, l0));
+                __syncthreads();
+                for (int t = tid; t < n; t += kZL) ZSWAP(MM(r, t), MM(l0, t));
+                if (tid == 0) {
+                    const int c = cnt[r];
+                    cnt[r] = cnt[l0];
+                    cnt[l0] = c;
+                }
+                __syncthreads();
+            }
+            for (int t = tid; t < l0; t += kZL)                      // column l0 leaves the window
+                if (ZNZ(t, l0)) cnt[t] -= 1;
+            --l0;
+            __syncthreads();
+        }
+        for (int j = wv; j <= l0; j += kZLW) {                        // off-diagonal nonzeros of column j, rows 0..l0
+            double c = 0.0;
+            for (int i = lane; i <= l0; i += 64) c += (i != j && ZNZ(i, j)) ? 1.0 : 0.0;
+            c = wave_sum(c);
+            if (lane == 0) cnt[j] = (int)c;
+        }
+        __syncthreads();
+        while (k0 < l0) {
+            if (tid == 0) s_idx = n;
+            __syncthreads();
+            for (int j = k0 + tid; j <= l0; j += kZL)
+                if (cnt[j] == 0) atomicMin(&s_idx, j);
+            __syncthreads();
+            const int c = s_idx;
+            __syncthreads();
+            if (c >= n) break;
+            if (c != k0) {
+                for (int t = tid; t <= l0; t += kZL) ZSWAP(MM(t, c), MM(t, k0));
+                __syncthreads();
+                for (int t = k0 + tid; t < n; t += kZL) ZSWAP(MM(c, t), MM(k0, t));
+                if (tid == 0) {
+                    const int q = cnt[c];
+                    cnt[c] = cnt[k0];
+                    cnt[k0] = q;
+                }
+                __syncthreads();
+            }
+            for (int t = k0 + 1 + tid; t <= l0; t += kZL)            // row k0 leaves the window
+                if (ZNZ(k0, t)) cnt[t] -= 1;
+            ++k0;
+            __syncthreads();
+        }
+        for (int pass = 0; pass < 16; ++pass) {
+            for (int j = k0 + wv; j <= l0; j += kZLW) {               // column norms: wave per column
+                double c = 0.0;
+                for (int i = k0 + lane; i <= l0; i += 64)
+                    if (i != j) c += qabs1(MM(i, j));
+                c = wave_sum(c);
+                if (lane == 0) cn[j] = c;
+            }
+            for (int i = k0 + tid; i <= l0; i += kZL) {               // row norms: thread per row
+                double r = 0.0;
+                for (int j = k0; j <= l0; ++j)
+                    if (j != i) r += qabs1(MM(i, j));
+                rn[i] = r;
+            }
+            if (tid == 0) s_idx = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += kZL) {
+                double f = 1.0;
+                if (i >= k0 && i <= l0) {
+                    double c = cn[i];
+                    const double r = rn[i];
+                    if (c != 0.0 && r != 0.0 && c < 1e300 && r < 1e300) {
+                        const double s0 = c + r;
+                        double g = r * 0.5;
+                        while (c < g) {
+                            f *= 2.0;
+                            c *= 4.0;
+                        }
+                        g = r * 2.0;
+                        while (c >= g) {
+                            f *= 0.5;
+                            c *= 0.25;
+                        }
+                        if ((c + r) / f >= 0.95 * s0) f = 1.0;
+                    }
+                }
+                fs[i] = f;
+                cn[i] = 1.0 / f;                                      // reuse: reciprocal factors (exact, powers of two)
+                if (f != 1.0) s_idx = 1;
+            }
+            __syncthreads();
+            const bool any = s_idx != 0;
+            __syncthreads();
+            if (!any) break;
+            for (int idx = tid; idx < n * n; idx += kZL) {
+                const int j = idx / n, i = idx - j * n;
+                M[idx] = qscale(M[idx], fs[j] * cn[i]);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+#undef ZNZ
+#undef ZSWAP
+    }
+
+    // ---- panels ----
+    const int rowtiles = np / 16;
+    for (int k = 0; k < n - 2; k += NB) {
+        const int jb = (NB < n - 2 - k) ? NB : (n - 2 - k);
+        for (int idx = tid; idx < 2 * NB * ldv + NB * NB; idx += kZL) Vs[idx] = {0.0, 0.0};   // V, Y, T
+        __syncthreads();
+        const int r = tid;                                            // this thread's row in the vector steps
+        const bool rin = r >= k + 1 && r < n;
+        for (int j = 0; j < jb; ++j) {
+            const int c = k + j;
+            // (a) column c with the right update of the earlier reflectors of this panel
+            if (rin) {
+                zq b = MM(r, c);
+                for (int jj = 0; jj < j; ++jj) b = qsub(b, qmulc(Ys[jj * ldv + r], Vs[jj * ldv + c]));
+                scr[r] = b;
+            }
+            __syncthreads();
+            if (j > 0) {
+                // (b1) w = V^H b, one wave per earlier reflector
+                if (wv < j) {
+                    zq acc = {0.0, 0.0};
+                    for (int rr = k + 1 + lane; rr < n; rr += 64) acc = qadd(acc, qcmul(Vs[wv * ldv + rr], scr[rr]));
+                    acc.re = wave_sum(acc.re);
+                    acc.im = wave_sum(acc.im);
+                    if (lane == 0) wsh[wv] = acc;
+                }
+                __syncthreads();
+                // (b2) w2 = T^H w
+                if (tid < j) {
+                    zq acc = {0.0, 0.0};
+                    for (int bb = 0; bb <= tid; ++bb) acc = qadd(acc, qcmul(Tsh[bb * NB + tid], wsh[bb]));
+                    w2sh[tid] = acc;
+                }
+                __syncthreads();
+            }
+            // (b3) b -= V w2, norm of the part below the subdiagonal
+            zq bv = {0.0, 0.0};
+            double part = 0.0;
+            if (rin) {
+                bv = scr[r];
+                for (int jj = 0; jj < j; ++jj) bv = qsub(bv, qmul(Vs[jj * ldv + r], w2sh[jj]));
+                if (r >= c + 2) part = fma(bv.re, bv.re, bv.im * bv.im);
+                if (r == c + 1) s_alpha = bv;
+            }
+            part = wave_sum(part);
+            if (lane == 0) red[wv] = part;
+            __syncthreads();
+            double xnorm2 = 0.0;
+#pragma unroll
+            for (int x = 0; x < kZLW; ++x) xnorm2 += red[x];
+            const zq alpha = s_alpha;
+            // (c) reflector (block-uniform scalars)
+            const bool act = !(xnorm2 == 0.0 && alpha.im == 0.0);
+            const double nrm = sqrt(fma(alpha.re, alpha.re, alpha.im * alpha.im) + xnorm2);
+            const double beta = act ? -copysign(nrm, alpha.re) : alpha.re;
+            const zq tau = act ? zq{(beta - alpha.re) / beta, -alpha.im / beta} : zq{0.0, 0.0};
+            const zq sc = act ? qdiv({1.0, 0.0}, {alpha.re - beta, alpha.im}) : zq{0.0, 0.0};
+            if (r < np) {
+                zq v = {0.0, 0.0};
+                if (r == c + 1) v = {1.0, 0.0};
+                else if (r >= c + 2 && r < n) v = qmul(bv, sc);
+                Vs[j * ldv + r] = v;
+                if (rin) {
+                    if (r <= c) MM(r, c) = bv;
+                    else if (r == c + 1) MM(r, c) = {beta, 0.0};
+                    else MM(r, c) = {0.0, 0.0};
+                }
+            }
+            __syncthreads();
+            // (d) z = V^H v for the earlier reflectors; y = A(k+1:n, c+1:n) v
+            if (wv < j) {
+                zq acc = {0.0, 0.0};
+                for (int rr = c + 1 + lane; rr < n; rr += 64) acc = qadd(acc, qcmul(Vs[wv * ldv + rr], Vs[j * ldv + rr]));
+                acc.re = wave_sum(acc.re);
+                acc.im = wave_sum(acc.im);
+                if (lane == 0) zsh[wv] = acc;
+            }
+            {
+                const int nr = n - k - 1;                             // rows k+1 .. n-1
+                const int rp = (nr + 63) & ~63;
+                const int ng = kZL / rp;                              // column groups (>= 1)
+                const int g = tid / rp, rr = tid - g * rp;
+                zq acc = {0.0, 0.0};
+                if (g < ng) {
+                    const int row = (rr < nr) ? k + 1 + rr : n - 1;   // clamped: always a valid address
+                    const zq* vj = Vs + j * ldv;
+                    int cc = c + 1 + g;
+                    for (; cc + 3 * ng < n; cc += 4 * ng) {
+                        const zq m0 = MM(row, cc), m1 = MM(row, cc + ng), m2 = MM(row, cc + 2 * ng), m3 = MM(row, cc + 3 * ng);
+                        acc = qadd(acc, qmul(m0, vj[cc]));
+                        acc = qadd(acc, qmul(m1, vj[cc + ng]));
+                        acc = qadd(acc, qmul(m2, vj[cc + 2 * ng]));
+                        acc = qadd(acc, qmul(m3, vj[cc + 3 * ng]));
+                    }
+                    for (; cc < n; cc += ng) acc = qadd(acc, qmul(MM(row, cc), vj[cc]));
+                }
+                scr[tid] = acc;
+                __syncthreads();
+                // (e) Y(:, j) = tau (y - Y z);  T(:, j) = -tau T z, T(j,j) = tau
+                if (rin) {
+                    const int r0 = r - k - 1;
+                    zq y = scr[r0];
+                    for (int x = 1; x < ng; ++x) y = qadd(y, scr[x * rp + r0]);
+                    for (int jj = 0; jj < j; ++jj) y = qsub(y, qmul(Ys[jj * ldv + r], zsh[jj]));
+                    Ys[j * ldv + r] = qmul(tau, y);
+                }
+                if (tid < j) {
+                    zq acc2 = {0.0, 0.0};
+                    for (int bb = tid; bb < j; ++bb) acc2 = qadd(acc2, qmul(Tsh[tid * NB + bb], zsh[bb]));
+                    Tsh[tid * NB + j] = qmul({-tau.re, -tau.im}, acc2);
+                }
+                if (tid == j) Tsh[j * NB + j] = tau;
+            }
+            __syncthreads();
+        }
+
+        // ---- (f) top rows of Y:  Y(0:k+1, :) = A(0:k+1, k+1:n) V T   (matrix cores) ----
+        {
+            const int ntile = (k + 1 + 15) / 16;
+            const int jjl = lane & 15, kk = lane >> 4;
+            for (int rt = wv; rt < ntile; rt += kZLW) {
+                v4d yr = {0.0, 0.0, 0.0, 0.0}, yi = {0.0, 0.0, 0.0, 0.0};
+                const int row = rt * 16 + (lane & 15);
+                const int rowc = (row < n) ? row : n - 1;
+                for (int cc0 = k + 1; cc0 < n; cc0 += 4) {
+                    const int cc = cc0 + kk;
+                    const int ccc = (cc < n) ? cc : n - 1;
+                    zq av = MM(rowc, ccc);
+                    zq bvv = (jjl < NB) ? Vs[jjl * ldv + ccc] : zq{0.0, 0.0};
+                    if (cc >= n) bvv = {0.0, 0.0};
+                    yr = mfma64(av.re, bvv.re, yr);
+                    yr = mfma64(-av.im, bvv.im, yr);
+                    yi = mfma64(av.re, bvv.im, yi);
+                    yi = mfma64(av.im, bvv.re, yi);
+                }
+                if (jjl < NB) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ro = rt * 16 + kk + 4 * q;
+                        if (ro <= k) Ys[jjl * ldv + ro] = {yr[q], yi[q]};
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (r <= k) {
+            // Y_top <- Y_top T (in place, last column first), then the panel columns' rows 0..k
+            for (int aa = jb - 1; aa >= 0; --aa) {
+                zq acc = {0.0, 0.0};
+                for (int bb = 0; bb <= aa; ++bb) acc = qadd(acc, qmul(Ys[bb * ldv + r], Tsh[bb * NB + aa]));
+                Ys[aa * ldv + r] = acc;
+            }
+            for (int j = 1; j < jb; ++j) {
+                const int c = k + j;
+                zq b = MM(r, c);
+                for (int jj = 0; jj < j; ++jj) b = qsub(b, qmulc(Ys[jj * ldv + r], Vs[jj * ldv + c]));
+                MM(r, c) = b;
+            }
+        }
+        __syncthreads();
+
+        // ---- (g, h) trailing columns: A <- A - Y V^H, then A <- A - V T^H (V^H A), tiles in registers ----
+        {
+            const int c0 = k + jb;
+            const int ncb = (n - c0 + 15) / 16;
+            const int gw = (rowtiles + TPW - 1) / TPW;                // waves per column block
+            int cbn = kZLW / gw;                                      // concurrent column blocks
+            if (cbn > 4) cbn = 4;
+            const int grp = wv / gw, wi = wv - grp * gw;
+            const int cl = lane & 15, kk = lane >> 4;
+            for (int cb0 = 0; cb0 < ncb; cb0 += cbn) {
+                const bool wact = grp < cbn && cb0 + grp < ncb;
+                const int cbase = c0 + (cb0 + grp) * 16;
+                const int col = cbase + cl;
+                const bool colok = wact && col < n;
+                const int colc = colok ? col : n - 1;
+                const int colv = (wact && col < np) ? col : np;       // Vs pad entry (zero) for columns beyond n
+                for (int idx = tid; idx < kZL; idx += kZL) scr[idx] = {0.0, 0.0};
+                __syncthreads();
+                v4d tr[TPW], ti[TPW];
+                if (wact) {
+                    v4d wr = {0.0, 0.0, 0.0, 0.0}, wim = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) {
+                        const int rt = wi * TPW + q;
+                        tr[q] = {0.0, 0.0, 0.0, 0.0};
+                        ti[q] = {0.0, 0.0, 0.0, 0.0};
+                        if (rt < rowtiles) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int row = rt * 16 + kk + 4 * g;
+                                const int rowc = (row < n) ? row : n - 1;
+                                const zq t = MM(rowc, colc);
+                                const bool ok = colok && row < n;
+                                tr[q][g] = ok ? t.re : 0.0;
+                                ti[q][g] = ok ? t.im : 0.0;
+                            }
+                            // right update: tile -= Y(rows, :) conj(V(cols, :))^T
+#pragma unroll
+                            for (int t = 0; t < NB / 4; ++t) {
+                                const int jj = 4 * t + kk;
+                                const zq y = Ys[jj * ldv + rt * 16 + cl];
+                                const zq v = Vs[jj * ldv + colv];
+                                tr[q] = mfma64(-y.re, v.re, tr[q]);
+                                tr[q] = mfma64(-y.im, v.im, tr[q]);
+                                ti[q] = mfma64(-y.im, v.re, ti[q]);
+                                ti[q] = mfma64(y.re, v.im, ti[q]);
+                            }
+                            // left update, first half: W += V(rows, :)^H tile   (the tile registers are the B operand)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const zq v = (cl < NB) ? Vs[cl * ldv + rt * 16 + 4 * t + kk] : zq{0.0, 0.0};
+                                wr = mfma64(v.re, tr[q][t], wr);
+                                wr = mfma64(v.im, ti[q][t], wr);
+                                wim = mfma64(v.re, ti[q][t], wim);
+                                wim = mfma64(-v.im, tr[q][t], wim);
+                            }
+                        }
+                    }
+                    // W(jj, col) of this column block: sum over the gw waves of the group
+                    double* wsum = reinterpret_cast<double*>(scr + grp * 256);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int jj = kk + 4 * g;
+                        lds_add(wsum + 2 * (jj * 16 + cl), wr[g]);
+                        lds_add(wsum + 2 * (jj * 16 + cl) + 1, wim[g]);
+                    }
+                }
+                __syncthreads();
+                // X = T^H W   (thread per element, then in place)
+                zq xv = {0.0, 0.0};
+                {
+                    const int g2 = tid >> 8, aa = (tid >> 4) & 15, cc = tid & 15;
+                    if (g2 < cbn && aa < NB) {
+                        for (int bb = 0; bb <= aa; ++bb) xv = qadd(xv, qcmul(Tsh[bb * NB + aa], scr[g2 * 256 + bb * 16 + cc]));
+                    }
+                }
+                __syncthreads();
+                scr[tid] = xv;
+                __syncthreads();
+                if (wact) {
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) {
+                        const int rt = wi * TPW + q;
+                        if (rt < rowtiles) {
+#pragma unroll
+                            for (int t = 0; t < NB / 4; ++t) {
+                                const int aa = 4 * t + kk;
+                                const zq v = Vs[aa * ldv + rt * 16 + cl];
+                                const zq x = scr[grp * 256 + aa * 16 + cl];
+                                tr[q] = mfma64(-v.re, x.re, tr[q]);
+                                tr[q] = mfma64(v.im, x.im, tr[q]);
+                                ti[q] = mfma64(-v.re, x.im, ti[q]);
+                                ti[q] = mfma64(-v.im, x.re, ti[q]);
+                            }
+                            if (colok) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const int row = rt * 16 + kk + 4 * g;
+                                    if (row < n) MM(row, col) = {tr[q][g], ti[q][g]};
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+#undef MM
+}
+
+// ---------------------------------------------------------------------------------------------------
+// multishift QR
+// ---------------------------------------------------------------------------------------------------
+constexpr int QW = 64;                  // window order
+constexpr int QLD = 65;                 // leading dimension of the LDS windows (odd: rows and columns conflict-free)
+constexpr int QM = 16;                  // bulges per chain (= wavefronts)
+constexpr int QNS = 8;                  // distinct shifts per sweep (each used twice)
+constexpr int QNBS = QW - 2 * QM - 1;   // time steps per window
+constexpr int QSMALL = 16;              // deflated blocks up to this order are finished by one wavefront
+constexpr int QSLD = 17;
+
+// All bulges advance through time steps t0..t1 inside the window (Wn = H[s : s+wd, s : s+wd]).  Wave = bulge.
+template <bool WITHU>
+__device__ __forceinline__ void zchase(zq* __restrict__ Wn, zq* __restrict__ Un, const zq* __restrict__ shifts, int s,
+                                       int wd, int l, int i, int t0, int t1, int lane, int wv) {
+    for (int t = t0; t <= t1; ++t) {
+        const int tb = t - 2 * wv;
+        const int p = l + tb;
+        const bool act = tb >= 0 && p <= i - 1;                        // wave-uniform
+        const int pw = p - s;
+        zq v2 = {0.0, 0.0}, tau = {0.0, 0.0};
+        if (act) {
+            zq a0, a1;
+            if (p == l) {
+                a0 = qsub(Wn[pw * QLD + pw], shifts[wv]);
+                a1 = Wn[(pw + 1) * QLD + pw];
+            } else {
+                a0 = Wn[pw * QLD + pw - 1];
+                a1 = Wn[(pw + 1) * QLD + pw - 1];
+            }
+            double beta;
+            zlarfg2_fast(a0, a1, beta, v2, tau);
+            // rows p, p+1 (lane = column): c <- H^H c
+            const zq r0 = Wn[pw * QLD + lane], r1 = Wn[(pw + 1) * QLD + lane];
+            const zq rs = qcmul(tau, qadd(r0, qcmul(v2, r1)));
+            if (lane >= pw && lane < wd) {
+                Wn[pw * QLD + lane] = qsub(r0, rs);
+                Wn[(pw + 1) * QLD + lane] = qsub(r1, qmul(rs, v2));
+            }
+            if (p > l && lane == pw - 1) {
+                Wn[pw * QLD + lane] = {beta, 0.0};
+                Wn[(pw + 1) * QLD + lane] = {0.0, 0.0};
+            }
+        }
+        __syncthreads();
+        if (act) {
+            // columns p, p+1 (lane = row): r <- r H
+            const int rmaxw = ((p + 2 < i) ? p + 2 : i) - s;
+            const zq c0 = Wn[lane * QLD + pw], c1 = Wn[lane * QLD + pw + 1];
+            const zq cs = qmul(tau, qadd(c0, qmul(c1, v2)));
+            if (lane <= rmaxw) {
+                Wn[lane * QLD + pw] = qsub(c0, cs);
+                Wn[lane * QLD + pw + 1] = qsub(c1, qmulc(cs, v2));
+            }
+            if (WITHU) {
+                const zq u0 = Un[lane * QLD + pw], u1 = Un[lane * QLD + pw + 1];
+                const zq us = qmul(tau, qadd(u0, qmul(u1, v2)));
+                if (lane < wd) {
+                    Un[lane * QLD + pw] = qsub(u0, us);
+                    Un[lane * QLD + pw + 1] = qsub(u1, qmulc(us, v2));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Deferred update of one side by the accumulated U (both as  out(f, g) = sum_k X(k, f) U'(k, g)  on the matrix cores):
+//   LEFT = false: rows [f0, f0 + nf) above the window:    H(f0 + f, s + g) <- sum_k H(f0 + f, s + k) U(k, g)
+//   LEFT = true : columns [f0, f0 + nf) right of it:      H(s + g, f0 + f) <- sum_k conj(U(k, g)) H(s + k, f0 + f)
+// X is staged in the (free) window array, 64 x 64 at a time; the next chunk's loads fly during the products.
+template <bool LEFT>
+__device__ __forceinline__ void zapply_u(zq* __restrict__ H, int n, zq* __restrict__ Xn, const zq* __restrict__ Un, int s,
+                                         int wd, int f0, int nf, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int ft = wv >> 2, gt = wv & 3;
+    const int cl = lane & 15, kk = lane >> 4;
+    const int ksteps = (wd + 3) / 4;
+    const int nchunk = (nf + 63) / 64;
+    zq pre[4];
+    auto gaddr = [&](int e, int fbase) -> int64_t {
+        // element e of a chunk: LEFT: f = e >> 6, k = e & 63 ; else k = e >> 6, f = e & 63
+        const int hi = e >> 6, lo = e & 63;
+        const int f = LEFT ? hi : lo, kx = LEFT ? lo : hi;
+        const int fc = (fbase + f < f0 + nf) ? fbase + f : f0 + nf - 1;
+        const int kc = (kx < wd) ? kx : wd - 1;
+        return LEFT ? ((int64_t)fc * n + (s + kc)) : ((int64_t)(s + kc) * n + fc);
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pre[u] = H[gaddr(tid + u * kZL, f0)];
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int fbase = f0 + ch * 64;
+        const int nfc = (f0 + nf - fbase < 64) ? f0 + nf - fbase : 64;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * kZL;
+            const int hi = e >> 6, lo = e & 63;
+            const int f = LEFT ? hi : lo, kx = LEFT ? lo : hi;
+            const bool ok = f < nfc && kx < wd;
+            Xn[kx * QLD + f] = ok ? pre[u] : zq{0.0, 0.0};
+        }
+        __syncthreads();
+        if (ch + 1 < nchunk) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pre[u] = H[gaddr(tid + u * kZL, fbase + 64)];
+        }
+        v4d dr = {0.0, 0.0, 0.0, 0.0}, di = {0.0, 0.0, 0.0, 0.0};
+        const bool tact = ft * 16 < nfc && gt * 16 < wd;
+        if (tact) {
+            for (int t = 0; t < ksteps; ++t) {
+                const zq x = Xn[(4 * t + kk) * QLD + ft * 16 + cl];
+                const zq u = Un[(4 * t + kk) * QLD + gt * 16 + cl];
+                const double ui = LEFT ? -u.im : u.im;
+                dr = mfma64(x.re, u.re, dr);
+                dr = mfma64(-x.im, ui, dr);
+                di = mfma64(x.re, ui, di);
+                di = mfma64(x.im, u.re, di);
+            }
+        }
+        __syncthreads();
+        if (tact) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Xn[(gt * 16 + cl) * QLD + ft * 16 + kk + 4 * q] = {dr[q], di[q]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * kZL;
+            const int hi = e >> 6, lo = e & 63;
+            const int f = LEFT ? hi : lo, g = LEFT ? lo : hi;
+            if (f < nfc && g < wd) {
+                const int64_t ad = LEFT ? ((int64_t)(fbase + f) * n + (s + g)) : ((int64_t)(s + g) * n + (fbase + f));
+                H[ad] = Xn[g * QLD + f];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, int n, double* __restrict__ w,
+                                                    int32_t* __restrict__ info_out) {
+    extern __shared__ double dynq[];
+    __shared__ int s_idx;
+    __shared__ int32_t s_info;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t mat = blockIdx.x;
+    if (info_out[mat] != 0) return;                                   // non-finite input, flagged by the reduction
+    zq* Wn = reinterpret_cast<zq*>(dynq);        // [QW][QLD]
+    zq* Un = Wn + QW * QLD;                      // [QW][QLD]
+    zq* Ss = Un + QW * QLD;                      // [QSMALL][QSLD]
+    zq* shifts = Ss + QSMALL * QSLD;             // [QM]
+    zq* sw = shifts + QM;                        // [QSMALL] eigenvalues of a small block
+    zq* H = reinterpret_cast<zq*>(work) + mat * (int64_t)n * n;
+    zq* wout = reinterpret_cast<zq*>(w) + mat * (int64_t)n;
+#define HG(r, c) H[(int64_t)(c) * n + (r)]
+    const double ulp = 2.220446049250313e-16;
+    const double safmin = 2.2250738585072014e-308;
+    const double smlnum = safmin * ((double)n / ulp);
+    int info = 0;
+    int i = n - 1;
+    int stall = 0;
+    while (i >= 0) {
+        // ---- deflation scan: largest k in (0, i] with a negligible subdiagonal ----
+        if (tid == 0) s_idx = 0;
+        __syncthreads();
+        for (int k = 1 + tid; k <= i; k += kZL) {
+            bool small = false;
+            const double hkk1 = qabs1(HG(k, k - 1));
+            if (hkk1 <= smlnum) {
+                small = true;
+            } else {
+                const zq hkk = HG(k, k), hk1k1 = HG(k - 1, k - 1);
+                double tst = qabs1(hk1k1) + qabs1(hkk);
+                if (tst == 0.0) {
+                    if (k - 2 >= 0) tst += qabs1(HG(k - 1, k - 2));
+                    if (k + 1 <= n - 1) tst += qabs1(HG(k + 1, k));
+                }
+                if (hkk1 <= ulp * tst) {
+                    const double hk1k = qabs1(HG(k - 1, k));
+                    const double ab = fmax(hkk1, hk1k), ba = fmin(hkk1, hk1k);
+                    const double df = qabs1(qsub(hk1k1, hkk));
+                    const double aa = fmax(qabs1(hkk), df), bb = fmin(qabs1(hkk), df);
+                    const double sm = aa + ab;
+                    if (ba * (ab / sm) <= fmax(smlnum, ulp * (bb * (aa / sm)))) small = true;
+                }
+            }
+            if (small) atomicMax(&s_idx, k);
+        }
+        __syncthreads();
+        const int l = s_idx;
+        if (l > 0 && tid == 0) HG(l, l - 1) = {0.0, 0.0};
+        __syncthreads();
+        if (l == i) {
+            if (tid == 0) wout[i] = HG(i, i);
+            --i;
+            stall = 0;
+            continue;
+        }
+        const int na = i - l + 1;
+        if (na <= QSMALL) {
+            // ---- small deflated block: one wavefront finishes it ----
+            for (int e = tid; e < na * na; e += kZL) {
+                const int c = e / na, r = e - c * na;
+                Ss[r * QSLD + c] = (r <= c + 1) ? HG(l + r, l + c) : zq{0.0, 0.0};
+            }
+            if (tid == 0) s_info = 0;
+            __syncthreads();
+            if (wv == 0) zhqr_wave(ZViewT<0, false>{Ss, QSLD}, na, lane, reinterpret_cast<double*>(sw), &s_info);
+            __syncthreads();
+            if (s_info != 0) {
+                info = l + s_info;
+                break;
+            }
+            if (tid < na) wout[l + tid] = sw[tid];
+            i = l - 1;
+            stall = 0;
+            __syncthreads();
+            continue;
+        }
+        if (++stall > 300) {
+            info = i + 1;
+            break;
+        }
+        // ---- shifts ----
+        if (stall % 6 == 0) {
+            if (tid < QNS) {
+                const int j = i - QNS + 1 + tid;
+                const zq d = HG(j, j);
+                sw[tid] = {d.re + 0.75 * qabs1(HG(j, j - 1)), d.im};
+            }
+            __syncthreads();
+        } else {
+            for (int e = tid; e < QNS * QNS; e += kZL) {
+                const int c = e / QNS, r = e - c * QNS;
+                Ss[r * QSLD + c] = (r <= c + 1) ? HG(i - QNS + 1 + r, i - QNS + 1 + c) : zq{0.0, 0.0};
+            }
+            if (tid == 0) s_info = 0;
+            __syncthreads();
+            if (wv == 0) zhqr_wave(ZViewT<0, false>{Ss, QSLD}, QNS, lane, reinterpret_cast<double*>(sw), &s_info);
+            __syncthreads();
+            if (s_info != 0) {                                        // shift generator stalled: fall back to the diagonal
+                if (tid < QNS) sw[tid] = HG(i - QNS + 1 + tid, i - QNS + 1 + tid);
+                __syncthreads();
+            }
+        }
+        if (tid < QM) shifts[tid] = sw[tid >> 1];
+        __syncthreads();
+        const int tmax = (i - 1 - l) + 2 * (QM - 1);
+        if (na <= QW) {
+            // ---- the whole active block fits one window: chase in place, nothing to update outside ----
+            for (int e = tid; e < QW * QW; e += kZL) {
+                const int c = e >> 6, r = e & 63;
+                const bool ok = r < na && c < na;
+                Wn[r * QLD + c] = ok ? HG(l + (r < na ? r : 0), l + (c < na ? c : 0)) : zq{0.0, 0.0};
+            }
+            __syncthreads();
+            zchase<false>(Wn, Un, shifts, l, na, l, i, 0, tmax, lane, wv);
+            for (int e = tid; e < QW * QW; e += kZL) {
+                const int c = e >> 6, r = e & 63;
+                if (r < na && c < na) HG(l + r, l + c) = Wn[r * QLD + c];
+            }
+            __syncthreads();
+            continue;
+        }
+        for (int kst = 0; kst * QNBS <= tmax; ++kst) {
+            const int t0 = kst * QNBS;
+            const int t1 = (t0 + QNBS - 1 < tmax) ? t0 + QNBS - 1 : tmax;
+            int s = l + t0 - 2 * (QM - 1) - 1;
+            if (s < l) s = l;
+            int e1 = l + t1 + 2;
+            if (e1 > i) e1 = i;
+            const int wd = e1 - s + 1;
+            for (int e = tid; e < QW * QW; e += kZL) {
+                const int c = e >> 6, r = e & 63;
+                const bool ok = r < wd && c < wd;
+                Wn[r * QLD + c] = ok ? HG(s + (r < wd ? r : 0), s + (c < wd ? c : 0)) : zq{0.0, 0.0};
+                Un[r * QLD + c] = (r == c) ? zq{1.0, 0.0} : zq{0.0, 0.0};
+            }
+            __syncthreads();
+            zchase<true>(Wn, Un, shifts, s, wd, l, i, t0, t1, lane, wv);
+            for (int e = tid; e < QW * QW; e += kZL) {
+                const int c = e >> 6, r = e & 63;
+                if (r < wd && c < wd) HG(s + r, s + c) = Wn[r * QLD + c];
+            }
+            __syncthreads();
+            if (s > l) zapply_u<false>(H, n, Wn, Un, s, wd, l, s - l, tid);
+            if (e1 < i) zapply_u<true>(H, n, Wn, Un, s, wd, e1 + 1, i - e1, tid);
+        }
+    }
+    if (info != 0) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        for (int j = tid; j < info; j += kZL) wout[j] = {qnan, qnan};
+    }
+    if (tid == 0) info_out[mat] = info;
+#undef HG
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static size_t zhess_lds_bytes(int n, int nb) {
+    const int ldv = zl_np(n) + 1;
+    return ((size_t)2 * nb * ldv + (size_t)nb * nb + kZL + 3 * nb) * sizeof(zq);
+}
+
+static int zhess_nb(int n) { return n <= 256 ? 16 : (n <= 512 ? 8 : 4); }
+
+size_t eig_zlarge_workspace_bytes(int64_t nmat, int n) { return (size_t)nmat * n * n * sizeof(zq); }
+
+int zhess_blocked_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, int64_t stride, double* w,
+                         int32_t* info, void* workspace, hipStream_t stream) {
+    const int nb = zhess_nb(n);
+    const size_t dyn = zhess_lds_bytes(n, nb);
+    const int balance = getenv("EGS_NO_BALANCE") ? 0 : 1;
+    const double* ap = static_cast<const double*>(a);
+    double* wk = static_cast<double*>(workspace);
+    auto launch = [&](auto kern) -> int {
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)dyn));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nmat), dim3(kZL), dyn, stream, ap, in_real ? 1 : 0, n, lda, stride, w,
+                           info, wk, balance);
+        EGS_LAUNCH_CHECK();
+        return 0;
+    };
+    if (nb == 16) return launch(zhess_blocked_kernel<16, 2>);
+    if (nb == 8) return launch(zhess_blocked_kernel<8, 2>);
+    return launch(zhess_blocked_kernel<4, 4>);
+}
+
+int zmsqr_launch(int64_t nmat, int n, double* w, int32_t* info, void* workspace, hipStream_t stream) {
+    const size_t dyn = ((size_t)2 * QW * QLD + QSMALL * QSLD + QM + QSMALL) * sizeof(zq);
+    EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zmsqr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dyn));
+    hipLaunchKernelGGL(zmsqr_kernel, dim3((unsigned)nmat), dim3(kZL), dyn, stream, static_cast<double*>(workspace), n, w,
+                       info);
+    EGS_LAUNCH_CHECK();
+    return 0;
+}
+
+int eig_zlarge_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, int64_t stride, double* w,
+                      int32_t* info, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (nmat == 0 || n == 0) return 0;
+    if (workspace_bytes < eig_zlarge_workspace_bytes(nmat, n)) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, eig_zlarge_workspace_bytes(nmat, n));
+        return -9;
+    }
+    const int st = zhess_blocked_launch(a, in_real, nmat, n, lda, stride, w, info, workspace, stream);
+    if (st) return st;
+    return zmsqr_launch(nmat, n, w, info, workspace, stream);
+}
+
+}  // namespace egs

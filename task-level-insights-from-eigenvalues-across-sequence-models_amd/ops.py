@@ -52,13 +52,18 @@ def device_props(device=0):
 
 
 # ---- K5 -------------------------------------------------------------------------------------------------
+_EIG_DTYPES = {torch.float32: _capi.EGS_F32, torch.float64: _capi.EGS_F64, torch.complex64: _capi.EGS_C64,
+               torch.complex128: _capi.EGS_C128}
+
+
 def eig_general_batched(a, workspace=None):
-    """Eigenvalues of a batch of dense matrices a[..., n, n] (float64 or complex128, row-major).
+    """Eigenvalues of a batch of dense matrices a[..., n, n] (row-major; single-precision input is widened on the
+    device and solved in double precision).
 
     Returns (w complex128 [..., n], info int32 [...]).  Replaces np.linalg.eigvals (analysis/eval_eig.py:296)."""
     _require_cuda(a, "a")
-    if a.dtype not in (torch.float64, torch.complex128):
-        raise TypeError(f"eig_general_batched computes in fp64: got {a.dtype}")
+    if a.dtype not in _EIG_DTYPES:
+        raise TypeError(f"eig_general_batched takes float32/float64/complex64/complex128 matrices: got {a.dtype}")
     if a.dim() < 2 or a.shape[-1] != a.shape[-2]:
         raise ValueError(f"expected [..., n, n], got {tuple(a.shape)}")
     n = a.shape[-1]
@@ -70,7 +75,7 @@ def eig_general_batched(a, workspace=None):
     if not a3.is_contiguous():
         a3 = a3.contiguous()
     nmat = a3.shape[0]
-    dtype = _capi.EGS_F64 if a.dtype == torch.float64 else _capi.EGS_C128
+    dtype = _EIG_DTYPES[a.dtype]
     w = torch.empty((nmat, n), dtype=torch.complex128, device=a.device)
     info = torch.empty((nmat,), dtype=torch.int32, device=a.device)
     need = lib().egs_eig_workspace_bytes(dtype, nmat, n)
@@ -79,6 +84,34 @@ def eig_general_batched(a, workspace=None):
         check(lib().egs_eig_general_batched(_ptr(a3), dtype, nmat, n, n, n * n, _ptr(w), _ptr(info), _ptr(ws),
                                             ws.numel() * ws.element_size(), _stream()), "egs_eig_general_batched")
     return w.reshape(*batch_shape, n), info.reshape(batch_shape)
+
+
+def hessenberg_general_batched(a):
+    """Stage 1 of the level-3 path (64 < n <= 1024): a [nmat, n, n] float64 / complex128 -> (h complex128 [nmat, n, n],
+    w, info).  Read row-major, h is LOWER Hessenberg with the eigenvalues of a (see include/eigspec.h); w / info are
+    the output buffers of stage 2 (info = n and a NaN spectrum already set for non-finite input)."""
+    _require_cuda(a, "a")
+    if a.dtype not in (torch.float64, torch.complex128):
+        raise TypeError(f"hessenberg_general_batched takes float64 / complex128: got {a.dtype}")
+    a = a.contiguous()
+    nmat, n, _ = a.shape
+    h = torch.empty((nmat, n, n), dtype=torch.complex128, device=a.device)
+    w = torch.empty((nmat, n), dtype=torch.complex128, device=a.device)
+    info = torch.empty((nmat,), dtype=torch.int32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().egs_hessenberg_general_batched(_ptr(a), _EIG_DTYPES[a.dtype], nmat, n, n, n * n, _ptr(h), _ptr(w),
+                                                   _ptr(info), _stream()), "egs_hessenberg_general_batched")
+    return h, w, info
+
+
+def hseqr_general_batched(h, w, info):
+    """Stage 2 of the level-3 path: multishift QR on the output of hessenberg_general_batched (h is destroyed)."""
+    _require_cuda(h, "h")
+    nmat, n, _ = h.shape
+    with torch.cuda.device(h.device):
+        check(lib().egs_hseqr_general_batched(_ptr(h), nmat, n, _ptr(w), _ptr(info), _stream()),
+              "egs_hseqr_general_batched")
+    return w, info
 
 
 def hessenberg_batched(a):

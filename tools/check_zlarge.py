@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Development check of the level-3 complex eigenvalue path (csrc/eig_zlarge.hip) on one GPU: Hessenberg stage
+against the NumPy prototype element by element (balancing off), spectra against LAPACK, timings at C5-like sizes."""
+import argparse, importlib, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--hess", default="100,128,200,256")
+ap.add_argument("--eig", default="100,128,200,256")
+ap.add_argument("--time", default="128:768,256:768")
+ap.add_argument("--nobalance", action="store_true")
+a = ap.parse_args()
+if a.nobalance:
+    os.environ["EGS_NO_BALANCE"] = "1"
+import torch
+import oracle as O
+from oracle import zms_proto as Z
+ops = importlib.import_module("task-level-insights-from-eigenvalues-across-sequence-models_amd").ops
+rng = np.random.default_rng(7)
+
+def rnd(n, m=1):
+    return (rng.standard_normal((m, n, n)) + 1j * rng.standard_normal((m, n, n))) / np.sqrt(n)
+
+def dplr(n, m):
+    lam_re = -np.abs(rng.standard_normal((m, n))) - 0.1
+    lam_im = rng.standard_normal((m, n)) * 5
+    pm = (rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))) * 0.2
+    ls = rng.uniform(np.log(1e-3), np.log(1e-1), m)
+    return np.stack([O.s4_dplr_ab(lam_re[i] + 1j * lam_im[i], pm[i], np.exp(ls[i])) for i in range(m)])
+
+if a.nobalance:
+    for n in [int(x) for x in a.hess.split(",") if x]:
+        A = rnd(n, 2)
+        h, w, info = ops.hessenberg_general_batched(torch.from_numpy(A).cuda())
+        torch.cuda.synchronize()
+        h = h.cpu().numpy()
+        nb = 16 if n <= 256 else (8 if n <= 512 else 4)
+        errs = []
+        for m in range(2):
+            ref = Z.hess_blocked(A[m].T, nb)          # the kernel reduces the transpose, stored column-major
+            got = h[m].T
+            errs.append(float(np.abs(got - ref).max()))
+        low = float(np.abs(np.tril(h[0].T, -2)).max())
+        print(json.dumps({"check": "hess_vs_proto", "n": n, "max_abs_diff": max(errs), "below_subdiag": low}), flush=True)
+
+for n in [int(x) for x in a.eig.split(",") if x]:
+    for kind, A in (("random", rnd(n, 3)), ("dplr", dplr(n, 3))):
+        t0 = time.perf_counter()
+        w, info = ops.eig_general_batched(torch.from_numpy(A).cuda())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        w = w.cpu().numpy()
+        ref = np.linalg.eigvals(A)
+        err = max(O.max_abs_dlambda(w[m], ref[m]) for m in range(A.shape[0]))
+        print(json.dumps({"check": "eig_vs_lapack", "n": n, "kind": kind, "max_abs_dlambda": err,
+                          "info": info.cpu().numpy().tolist(), "first_call_s": dt}), flush=True)
+
+for spec in [x for x in a.time.split(",") if x]:
+    n, m = (int(v) for v in spec.split(":"))
+    A = torch.from_numpy(np.tile(rnd(n, 8), (m // 8, 1, 1))).cuda()
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        h, w, info = ops.hessenberg_general_batched(A); torch.cuda.synchronize(); t1 = time.perf_counter()
+        ops.hseqr_general_batched(h, w, info); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(json.dumps({"check": "time", "n": n, "nmat": m, "hess_ms": (t1 - t0) * 1e3, "qr_ms": (t2 - t1) * 1e3,
+                      "unconverged": int((info != 0).sum())}), flush=True)
