@@ -100,10 +100,15 @@ int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int l
  *   egs_hessenberg_general_batched : a (dtype as above, row-major, not modified) -> h, complex128[nmat, n, n]: the
  *       upper-Hessenberg reduction of the TRANSPOSE of each (balanced) matrix, stored column-major -- i.e. read as a
  *       row-major [n, n] array, h is LOWER Hessenberg and has the eigenvalues of a.  info[m] = n flags NaN / Inf input.
- *   egs_hseqr_general_batched      : h as produced above (destroyed) -> w complex128[nmat, n], info. */
+ *   egs_hseqr_general_batched      : h as produced above (destroyed) -> w complex128[nmat, n], info.  Diagnostics:
+ *       phase_cycles = NULL, or device double[nmat, 12] receiving per matrix the shader-clock cycles spent in the
+ *       deflation scans, shift generator / small blocks, window load + store, bulge chase, deferred matrix-core
+ *       updates and single-window sweeps, then the number of sweeps and of windows, then the chase split as wave 0
+ *       sees it (row phase, barrier, column phase, barrier). */
 int egs_hessenberg_general_batched(const void* a, int dtype, int64_t nmat, int n, int lda, int64_t stride, double* h,
                                    double* w, int32_t* info, egs_stream_t stream);
-int egs_hseqr_general_batched(double* h, int64_t nmat, int n, double* w, int32_t* info, egs_stream_t stream);
+int egs_hseqr_general_batched(double* h, int64_t nmat, int n, double* w, int32_t* info, double* phase_cycles,
+                              egs_stream_t stream);
 
 /* The two stages of the real LDS-resident solver (dtype EGS_F64, n <= 64), exposed separately like LAPACK's
  * xGEHRD / xHSEQR so that callers (and bench.py) can time or reuse them individually.

@@ -36,7 +36,7 @@ SIGNATURES = {
     "egs_eig_workspace_bytes": (_sz, [_i, _i64, _i]),
     "egs_eig_general_batched": (_i, [_vp, _i, _i64, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "egs_hessenberg_general_batched": (_i, [_vp, _i, _i64, _i, _i, _i64, _vp, _vp, _vp, _vp]),
-    "egs_hseqr_general_batched": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "egs_hseqr_general_batched": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "egs_hessenberg_batched": (_i, [_vp, _i64, _i, _i, _i64, _vp, _vp]),
     "egs_hseqr_batched": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "egs_mamba2_lambda": (_i, [_vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -57,7 +57,7 @@ size_t eig_cplx_workspace_bytes(int64_t, int);
 int eig_cplx_launch(const void*, bool, int64_t, int, int, int64_t, double*, int32_t*, void*, size_t, hipStream_t);
 size_t eig_zlarge_workspace_bytes(int64_t, int);
 int zhess_blocked_launch(const void*, bool, int64_t, int, int, int64_t, double*, int32_t*, void*, hipStream_t);
-int zmsqr_launch(int64_t, int, double*, int32_t*, void*, hipStream_t);
+int zmsqr_launch(int64_t, int, double*, int32_t*, void*, double*, hipStream_t);
 
 // float / complex64 -> double / complex128, packed [nmat, n, n] (the single-precision entry of the dense solver)
 __global__ void widen_f32_kernel(const float* __restrict__ src, double* __restrict__ dst, int64_t nmat, int n, int lda,
@@ -199,14 +199,15 @@ int egs_hessenberg_general_batched(const void* a, int dtype, int64_t nmat, int n
     return zhess_blocked_launch(a, dtype == EGS_F64, nmat, n, lda, stride, w, info, h, as_stream(stream));
 }
 
-int egs_hseqr_general_batched(double* h, int64_t nmat, int n, double* w, int32_t* info, egs_stream_t stream) {
+int egs_hseqr_general_batched(double* h, int64_t nmat, int n, double* w, int32_t* info, double* phase_cycles,
+                              egs_stream_t stream) {
     EGS_ARG(nmat >= 0, 2);
     EGS_ARG(n > 64 && n <= 1024, 3);
     if (nmat == 0) return 0;
     EGS_ARG(h != nullptr, 1);
     EGS_ARG(w != nullptr, 4);
     EGS_ARG(info != nullptr, 5);
-    return zmsqr_launch(nmat, n, w, info, h, as_stream(stream));
+    return zmsqr_launch(nmat, n, w, info, h, phase_cycles, as_stream(stream));
 }
 
 int egs_hessenberg_batched(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h,

@@ -27,7 +27,7 @@ template <bool INREAL>
 __global__ __launch_bounds__(kZH) void zhess64_kernel(const double* __restrict__ a, int n, int lda, int64_t stride,
                                                       double* __restrict__ hout, double* __restrict__ w,
                                                       int32_t* __restrict__ info, int balance) {
-    extern __shared__ double dynz[];
+    extern __shared__ __attribute__((aligned(16))) double dynz[];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t mat = blockIdx.x;
@@ -299,7 +299,7 @@ __device__ __forceinline__ void zhqr_run(const V H, const double* __restrict__ s
 __global__ __launch_bounds__(256) void zhqr_wave_kernel(const double* __restrict__ hin, int64_t nmat, int n,
                                                         double* __restrict__ w, int32_t* __restrict__ info,
                                                         int waves_per_block) {
-    extern __shared__ double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const int64_t mat = (int64_t)blockIdx.x * waves_per_block + wave;

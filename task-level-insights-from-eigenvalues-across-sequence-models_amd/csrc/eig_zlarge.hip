@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
                                                             int64_t stride, double* __restrict__ w,
                                                             int32_t* __restrict__ info_out, double* __restrict__ work,
                                                             int balance) {
-    extern __shared__ double dynl[];
+    extern __shared__ __attribute__((aligned(16))) double dynl[];
     __shared__ double red[kZLW];
     __shared__ zq s_alpha;
     __shared__ int s_idx;
@@ -280,8 +280,8 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
             const bool act = !(xnorm2 == 0.0 && alpha.im == 0.0);
             const double nrm = sqrt(fma(alpha.re, alpha.re, alpha.im * alpha.im) + xnorm2);
             const double beta = act ? -copysign(nrm, alpha.re) : alpha.re;
-            const zq tau = act ? zq{(beta - alpha.re) / beta, -alpha.im / beta} : zq{0.0, 0.0};
-            const zq sc = act ? qdiv({1.0, 0.0}, {alpha.re - beta, alpha.im}) : zq{0.0, 0.0};
+            const zq tau = qsel(act, zq{(beta - alpha.re) / beta, -alpha.im / beta}, zq{0.0, 0.0});
+            const zq sc = qsel(act, qdiv({1.0, 0.0}, {alpha.re - beta, alpha.im}), zq{0.0, 0.0});
             if (r < np) {
                 zq v = {0.0, 0.0};
                 if (r == c + 1) v = {1.0, 0.0};
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
                     const int cc = cc0 + kk;
                     const int ccc = (cc < n) ? cc : n - 1;
                     zq av = MM(rowc, ccc);
-                    zq bvv = (jjl < NB) ? Vs[jjl * ldv + ccc] : zq{0.0, 0.0};
+                    zq bvv = qsel(jjl < NB, Vs[(jjl < NB ? jjl : 0) * ldv + ccc], zq{0.0, 0.0});
                     if (cc >= n) bvv = {0.0, 0.0};
                     yr = mfma64(av.re, bvv.re, yr);
                     yr = mfma64(-av.im, bvv.im, yr);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
                             // left update, first half: W += V(rows, :)^H tile   (the tile registers are the B operand)
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                const zq v = (cl < NB) ? Vs[cl * ldv + rt * 16 + 4 * t + kk] : zq{0.0, 0.0};
+                                const zq v = qsel(cl < NB, Vs[(cl < NB ? cl : 0) * ldv + rt * 16 + 4 * t + kk], zq{0.0, 0.0});
                                 wr = mfma64(v.re, tr[q][t], wr);
                                 wr = mfma64(v.im, ti[q][t], wr);
                                 wim = mfma64(v.re, ti[q][t], wim);
@@ -564,6 +564,178 @@ __device__ __forceinline__ void zchase(zq* __restrict__ Wn, zq* __restrict__ Un,
     }
 }
 
+// Complex Givens rotation with a REAL cosine:  Q = [[c, s], [-conj(s), c]],  Q (a0; a1) = (rho; 0).
+// Applying it to a pair of complex numbers costs 12 fused multiply-adds (the 2-element Householder form: 18).
+__device__ __forceinline__ void zgivens(zq a0, zq a1, double& c, zq& sn, zq& rho) {
+    const double tiny = 1e-300;
+    const double n0 = fma(a0.re, a0.re, a0.im * a0.im);
+    const double n1 = fma(a1.re, a1.re, a1.im * a1.im);
+    const double nn = n0 + n1;
+    const double rn = fast_rsqrt(fmax(nn, tiny));                       // 1 / norm
+    const double r0 = fast_rsqrt(fmax(n0, tiny));                       // 1 / |a0|
+    const bool z0 = n0 < tiny;
+    const bool zz = nn < tiny;                                          // nothing to rotate: identity
+    const zq sg = qsel(z0, zq{1.0, 0.0}, qscale(a0, r0));                   // a0 / |a0|
+    c = zz ? 1.0 : (z0 ? 0.0 : n0 * r0 * rn);
+    sn = qsel(zz, zq{0.0, 0.0}, qscale(qmulc(sg, a1), rn));                 // sg conj(a1) / norm
+    rho = zz ? a0 : qscale(sg, nn * rn);
+}
+// rows:    (x0; x1) <- Q (x0; x1)
+__device__ __forceinline__ void zrot_rows(double c, zq sn, zq x0, zq x1, zq& y0, zq& y1) {
+    y0 = {fma(c, x0.re, fma(sn.re, x1.re, -sn.im * x1.im)), fma(c, x0.im, fma(sn.re, x1.im, sn.im * x1.re))};
+    y1 = {fma(c, x1.re, -fma(sn.re, x0.re, sn.im * x0.im)), fma(c, x1.im, -fma(sn.re, x0.im, -sn.im * x0.re))};
+}
+// columns: (x0, x1) <- (x0, x1) Q^H
+__device__ __forceinline__ void zrot_cols(double c, zq sn, zq x0, zq x1, zq& y0, zq& y1) {
+    y0 = {fma(c, x0.re, fma(sn.re, x1.re, sn.im * x1.im)), fma(c, x0.im, fma(sn.re, x1.im, -sn.im * x1.re))};
+    y1 = {fma(c, x1.re, -fma(sn.re, x0.re, -sn.im * x0.im)), fma(c, x1.im, -fma(sn.re, x0.im, sn.im * x0.re))};
+}
+
+// The chase as it runs now (the first version above computed every 2-element Householder reflector in all 64 lanes
+// of its wave -- 28 % of the issued fp64 instructions -- on the critical path of every step):
+//   * rotations instead of reflectors (12 instead of 18 multiply-adds per element pair);
+//   * wave = bulge for the bulk work: row operation on the window and column operation on U in phase 1, column
+//     operation on the window in phase 2;
+//   * the rotation of step t+1 is computed DURING phase 2 of step t by one lane per bulge (lanes 0..3 of waves 0..3)
+//     from three numbers the row phase leaves in a mailbox: the two entries of row p+1 it has just produced and the
+//     subdiagonal entry below them.  The two window entries that become (rho, 0) are written by that lane and skipped
+//     by the bulk column operation, so the scalar chain and the bulk update never touch the same element.
+// prm: [2][QM][3] = ({c, -}, s, rho) per bulge, double-buffered by step parity;  mbx: [2][QM][3].
+// rho of step t is put into the window by the bulge's own wave at the start of phase 1 (the wave of the bulge behind
+// takes it from the table), so no window element is written by one wave and read by another inside a phase.
+template <bool WITHU>
+__device__ __forceinline__ void zchase3(zq* __restrict__ Wn, zq* __restrict__ Un, zq* __restrict__ prm,
+                                        zq* __restrict__ mbx, const zq* __restrict__ shifts, int s, int wd, int l, int i,
+                                        int t0, int t1, int lane, int wv, const bool prof, long long (&cst)[4]) {
+    long long tl = prof ? (long long)__builtin_readcyclecounter() : 0;
+#define CSTAMP(k)                                                  \
+    if (prof) {                                                    \
+        const long long now_ = __builtin_readcyclecounter();       \
+        cst[k] += now_ - tl;                                       \
+        tl = now_;                                                 \
+    }
+    const int bg = 4 * (wv & 3) + (lane & 3);                          // look-ahead lane -> bulge
+    const bool lwave = wv < 4;
+    if (lwave) {                                                       // prologue: rotations of step t0 from the window
+        const int tb = t0 - 2 * bg;
+        const int p = l + tb;
+        const bool act = tb >= 0 && p <= i - 1;
+        const int pw = act ? p - s : 1;
+        const bool intro = act && p == l;
+        const int pc = (pw >= 1) ? pw : 1;
+        const zq a0 = qsel(intro, qsub(Wn[pw * QLD + pw], shifts[bg]), Wn[pc * QLD + pc - 1]);
+        const zq a1 = qsel(intro, Wn[(pw + 1) * QLD + pw], Wn[(pc + 1) * QLD + pc - 1]);
+        double c;
+        zq sn, rho;
+        zgivens(a0, a1, c, sn, rho);
+        if (act && lane < 4) {
+            prm[((t0 & 1) * QM + bg) * 3 + 0] = {c, 0.0};
+            prm[((t0 & 1) * QM + bg) * 3 + 1] = sn;
+            prm[((t0 & 1) * QM + bg) * 3 + 2] = rho;
+            if (bg + 1 < QM) mbx[((t0 & 1) * QM + bg + 1) * 3 + 2] = rho;
+        }
+    }
+    __syncthreads();
+    const int b = wv;
+    zq ucar = {0.0, 0.0};
+    bool ucv = false;                                                  // ucar holds column p of U
+    for (int t = t0; t <= t1; ++t) {
+        const int par = t & 1;
+        const int tb = t - 2 * b;
+        const int p = l + tb;
+        const bool act = tb >= 0 && p <= i - 1;                        // wave-uniform
+        const int pw = p - s;
+        double c = 1.0;
+        zq sn = {0.0, 0.0};
+        // ---- phase 1: rows p, p+1 of the window (lane = column), columns p, p+1 of U (lane = row), mailbox ----
+        if (act) {
+            c = prm[(par * QM + b) * 3 + 0].re;
+            sn = prm[(par * QM + b) * 3 + 1];
+            const zq rho = prm[(par * QM + b) * 3 + 2];
+            const zq r0 = Wn[pw * QLD + lane], r1 = Wn[(pw + 1) * QLD + lane];
+            zq y0, y1;
+            zrot_rows(c, sn, r0, r1, y0, y1);
+            // column p-1 holds the bulge this rotation annihilates: lane p-1 stores (rho, 0) with the same two stores
+            const bool bl_lane = tb >= 1 && lane == pw - 1;
+            if ((lane >= pw && lane < wd) || bl_lane) {
+                Wn[pw * QLD + lane] = qsel(bl_lane, rho, y0);
+                Wn[(pw + 1) * QLD + lane] = qsel(bl_lane, zq{0.0, 0.0}, y1);
+            }
+            // mailbox for the look-ahead lane: the new (p+1, p), (p+1, p+1) and, unless the bulge in front supplies its
+            // rho, the subdiagonal entry (p+2, p+1)
+            const bool ahead = b >= 1 && p + 2 <= i - 1;               // a bulge sits at p + 2 this step
+            zq mb = y1;
+            int nmb = 2;
+            if (!ahead) {
+                const int rb = (pw + 2 < wd) ? pw + 2 : wd - 1;
+                const zq bl = Wn[rb * QLD + pw + 1];
+                mb = qsel(lane == pw + 2, bl, mb);
+                nmb = 3;
+            }
+            if (lane >= pw && lane < pw + nmb) mbx[(par * QM + b) * 3 + (lane - pw)] = mb;
+        }
+        CSTAMP(0)
+        __syncthreads();
+        CSTAMP(1)
+        // ---- phase 2: columns p, p+1 of the window (lane = row); next rotation by the look-ahead lanes ----
+        if (lwave) {
+            __builtin_amdgcn_s_setprio(3);                             // the scalar chain is the critical path of the step
+            const int tb1 = t + 1 - 2 * bg;
+            const int p1 = l + tb1;
+            const bool act1 = t < t1 && tb1 >= 0 && p1 <= i - 1;
+            const bool intro = act1 && tb1 == 0;
+            const int pwn = act1 ? p1 - s : 1;
+            const double lc = prm[(par * QM + bg) * 3 + 0].re;
+            const zq ls = prm[(par * QM + bg) * 3 + 1];
+            const zq x00 = mbx[(par * QM + bg) * 3 + 0], x01 = mbx[(par * QM + bg) * 3 + 1], x11 = mbx[(par * QM + bg) * 3 + 2];
+            const zq i0 = Wn[pwn * QLD + pwn], i1 = Wn[(pwn + 1) * QLD + pwn];
+            // column operation on rows p+1 (entries x00, x01) and p+2 (entries 0, x11), first column only
+            zq a0 = {fma(lc, x00.re, fma(ls.re, x01.re, ls.im * x01.im)), fma(lc, x00.im, fma(ls.re, x01.im, -ls.im * x01.re))};
+            zq a1 = {fma(ls.re, x11.re, ls.im * x11.im), fma(ls.re, x11.im, -ls.im * x11.re)};
+            a0 = qsel(intro, qsub(i0, shifts[bg]), a0);
+            a1 = qsel(intro, i1, a1);
+            double nc;
+            zq nsn, nrho;
+            zgivens(a0, a1, nc, nsn, nrho);
+            if (act1 && lane < 4) {
+                prm[((par ^ 1) * QM + bg) * 3 + 0] = {nc, 0.0};
+                prm[((par ^ 1) * QM + bg) * 3 + 1] = nsn;
+                prm[((par ^ 1) * QM + bg) * 3 + 2] = nrho;
+                if (bg + 1 < QM) mbx[((par ^ 1) * QM + bg + 1) * 3 + 2] = nrho;   // "below" of the bulge behind, next step
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (act) {
+            const int rmaxw = ((p + 2 < i) ? p + 2 : i) - s;
+            const zq c0 = Wn[lane * QLD + pw], c1 = Wn[lane * QLD + pw + 1];
+            zq y0, y1;
+            zrot_cols(c, sn, c0, c1, y0, y1);
+            if (lane <= rmaxw) {
+                Wn[lane * QLD + pw] = y0;
+                Wn[lane * QLD + pw + 1] = y1;
+            }
+            if (WITHU) {
+                // column p of U is still in this wave's registers from the previous step (no other bulge touches it)
+                const zq ul = Un[lane * QLD + pw];
+                const zq u0 = qsel(ucv, ucar, ul);
+                const zq u1 = Un[lane * QLD + pw + 1];
+                zq v0, v1;
+                zrot_cols(c, sn, u0, u1, v0, v1);
+                ucv = t < t1 && p + 1 <= i - 1;                        // the bulge moves on inside this window
+                ucar = v1;
+                if (lane < wd) {
+                    Un[lane * QLD + pw] = v0;
+                    if (!ucv) Un[lane * QLD + pw + 1] = v1;
+                }
+            }
+        }
+        CSTAMP(2)
+        __syncthreads();
+        CSTAMP(3)
+    }
+#undef CSTAMP
+}
+
 // Deferred update of one side by the accumulated U (both as  out(f, g) = sum_k X(k, f) U'(k, g)  on the matrix cores):
 //   LEFT = false: rows [f0, f0 + nf) above the window:    H(f0 + f, s + g) <- sum_k H(f0 + f, s + k) U(k, g)
 //   LEFT = true : columns [f0, f0 + nf) right of it:      H(s + g, f0 + f) <- sum_k conj(U(k, g)) H(s + k, f0 + f)
@@ -596,26 +768,33 @@ __device__ __forceinline__ void zapply_u(zq* __restrict__ H, int n, zq* __restri
             const int hi = e >> 6, lo = e & 63;
             const int f = LEFT ? hi : lo, kx = LEFT ? lo : hi;
             const bool ok = f < nfc && kx < wd;
-            Xn[kx * QLD + f] = ok ? pre[u] : zq{0.0, 0.0};
+            Xn[kx * QLD + f] = qsel(ok, pre[u], zq{0.0, 0.0});
         }
         __syncthreads();
         if (ch + 1 < nchunk) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) pre[u] = H[gaddr(tid + u * kZL, fbase + 64)];
         }
-        v4d dr = {0.0, 0.0, 0.0, 0.0}, di = {0.0, 0.0, 0.0, 0.0};
+        // complex product with three real ones (Gauss):  k1 = (xr + xi) ur,  k2 = xr (ui - ur),  k3 = xi (ur + ui);
+        // re = k1 - k3,  im = k1 + k2  -- the fp64 matrix pipe is what bounds this phase, a quarter of it is saved
+        v4d k1 = {0.0, 0.0, 0.0, 0.0}, k2 = {0.0, 0.0, 0.0, 0.0}, k3 = {0.0, 0.0, 0.0, 0.0};
         const bool tact = ft * 16 < nfc && gt * 16 < wd;
         if (tact) {
-            for (int t = 0; t < ksteps; ++t) {
+            // U is banded (bulges move down: k - g <= QM, g - k <= QNBS): skip the k-steps that only meet zeros
+            int tlo = (gt * 16 - QNBS) >> 2;
+            if (tlo < 0) tlo = 0;
+            int thi = (gt * 16 + 15 + QM + 4) >> 2;
+            if (thi > ksteps) thi = ksteps;
+            for (int t = tlo; t < thi; ++t) {
                 const zq x = Xn[(4 * t + kk) * QLD + ft * 16 + cl];
                 const zq u = Un[(4 * t + kk) * QLD + gt * 16 + cl];
                 const double ui = LEFT ? -u.im : u.im;
-                dr = mfma64(x.re, u.re, dr);
-                dr = mfma64(-x.im, ui, dr);
-                di = mfma64(x.re, ui, di);
-                di = mfma64(x.im, u.re, di);
+                k1 = mfma64(x.re + x.im, u.re, k1);
+                k2 = mfma64(x.re, ui - u.re, k2);
+                k3 = mfma64(x.im, u.re + ui, k3);
             }
         }
+        const v4d dr = k1 - k3, di = k1 + k2;
         __syncthreads();
         if (tact) {
 #pragma unroll
@@ -636,9 +815,12 @@ __device__ __forceinline__ void zapply_u(zq* __restrict__ H, int n, zq* __restri
     }
 }
 
+// prof: NULL, or double[nmat][12] receiving shader-clock cycles per phase (scan, shift generator / small blocks,
+// window load + store, chase, deferred updates, single-window chase), the sweep / stage counts, and the split of the
+// chase as wave 0 sees it (row phase, barrier, column phase, barrier).
 __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, int n, double* __restrict__ w,
-                                                    int32_t* __restrict__ info_out) {
-    extern __shared__ double dynq[];
+                                                    int32_t* __restrict__ info_out, double* __restrict__ prof) {
+    extern __shared__ __attribute__((aligned(16))) double dynq[];
     __shared__ int s_idx;
     __shared__ int32_t s_info;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -649,6 +831,8 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
     zq* Ss = Un + QW * QLD;                      // [QSMALL][QSLD]
     zq* shifts = Ss + QSMALL * QSLD;             // [QM]
     zq* sw = shifts + QM;                        // [QSMALL] eigenvalues of a small block
+    zq* prm = sw + QSMALL;                       // [2][QM][3] rotation parameters of the chase
+    zq* mbx = prm + 6 * QM;                      // [2][QM][3] look-ahead mailbox
     zq* H = reinterpret_cast<zq*>(work) + mat * (int64_t)n * n;
     zq* wout = reinterpret_cast<zq*>(w) + mat * (int64_t)n;
 #define HG(r, c) H[(int64_t)(c) * n + (r)]
@@ -658,6 +842,16 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
     int info = 0;
     int i = n - 1;
     int stall = 0;
+    long long pacc0 = 0, pacc1 = 0, pacc2 = 0, pacc3 = 0, pacc4 = 0, pacc5 = 0, plast = 0;
+    int nsweep = 0, nstage = 0;
+    long long cst[4] = {0, 0, 0, 0};
+#define ZSTAMP(acc)                                            \
+    if (prof) {                                                \
+        const long long now_ = __builtin_readcyclecounter();   \
+        acc += now_ - plast;                                   \
+        plast = now_;                                          \
+    }
+    if (prof) plast = __builtin_readcyclecounter();
     while (i >= 0) {
         // ---- deflation scan: largest k in (0, i] with a negligible subdiagonal ----
         if (tid == 0) s_idx = 0;
@@ -696,11 +890,12 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
             continue;
         }
         const int na = i - l + 1;
+        ZSTAMP(pacc0)
         if (na <= QSMALL) {
             // ---- small deflated block: one wavefront finishes it ----
             for (int e = tid; e < na * na; e += kZL) {
                 const int c = e / na, r = e - c * na;
-                Ss[r * QSLD + c] = (r <= c + 1) ? HG(l + r, l + c) : zq{0.0, 0.0};
+                Ss[r * QSLD + c] = qsel(r <= c + 1, HG(l + r, l + c), zq{0.0, 0.0});
             }
             if (tid == 0) s_info = 0;
             __syncthreads();
@@ -714,6 +909,7 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
             i = l - 1;
             stall = 0;
             __syncthreads();
+            ZSTAMP(pacc1)
             continue;
         }
         if (++stall > 300) {
@@ -731,11 +927,11 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
         } else {
             for (int e = tid; e < QNS * QNS; e += kZL) {
                 const int c = e / QNS, r = e - c * QNS;
-                Ss[r * QSLD + c] = (r <= c + 1) ? HG(i - QNS + 1 + r, i - QNS + 1 + c) : zq{0.0, 0.0};
+                Ss[r * QSLD + c] = qsel(r <= c + 1, HG(i - QNS + 1 + r, i - QNS + 1 + c), zq{0.0, 0.0});
             }
             if (tid == 0) s_info = 0;
             __syncthreads();
-            if (wv == 0) zhqr_wave(ZViewT<0, false>{Ss, QSLD}, QNS, lane, reinterpret_cast<double*>(sw), &s_info);
+            if (wv == 0) zhqr_wave<ZViewT<0, false>, true>(ZViewT<0, false>{Ss, QSLD}, QNS, lane, reinterpret_cast<double*>(sw), &s_info);
             __syncthreads();
             if (s_info != 0) {                                        // shift generator stalled: fall back to the diagonal
                 if (tid < QNS) sw[tid] = HG(i - QNS + 1 + tid, i - QNS + 1 + tid);
@@ -744,21 +940,24 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
         }
         if (tid < QM) shifts[tid] = sw[tid >> 1];
         __syncthreads();
+        ZSTAMP(pacc1)
+        ++nsweep;
         const int tmax = (i - 1 - l) + 2 * (QM - 1);
         if (na <= QW) {
             // ---- the whole active block fits one window: chase in place, nothing to update outside ----
             for (int e = tid; e < QW * QW; e += kZL) {
                 const int c = e >> 6, r = e & 63;
                 const bool ok = r < na && c < na;
-                Wn[r * QLD + c] = ok ? HG(l + (r < na ? r : 0), l + (c < na ? c : 0)) : zq{0.0, 0.0};
+                Wn[r * QLD + c] = qsel(ok, HG(l + (r < na ? r : 0), l + (c < na ? c : 0)), zq{0.0, 0.0});
             }
             __syncthreads();
-            zchase<false>(Wn, Un, shifts, l, na, l, i, 0, tmax, lane, wv);
+            zchase3<false>(Wn, Un, prm, mbx, shifts, l, na, l, i, 0, tmax, lane, wv, false, cst);
             for (int e = tid; e < QW * QW; e += kZL) {
                 const int c = e >> 6, r = e & 63;
                 if (r < na && c < na) HG(l + r, l + c) = Wn[r * QLD + c];
             }
             __syncthreads();
+            ZSTAMP(pacc5)
             continue;
         }
         for (int kst = 0; kst * QNBS <= tmax; ++kst) {
@@ -772,18 +971,23 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
             for (int e = tid; e < QW * QW; e += kZL) {
                 const int c = e >> 6, r = e & 63;
                 const bool ok = r < wd && c < wd;
-                Wn[r * QLD + c] = ok ? HG(s + (r < wd ? r : 0), s + (c < wd ? c : 0)) : zq{0.0, 0.0};
-                Un[r * QLD + c] = (r == c) ? zq{1.0, 0.0} : zq{0.0, 0.0};
+                Wn[r * QLD + c] = qsel(ok, HG(s + (r < wd ? r : 0), s + (c < wd ? c : 0)), zq{0.0, 0.0});
+                Un[r * QLD + c] = zq{(r == c) ? 1.0 : 0.0, 0.0};
             }
             __syncthreads();
-            zchase<true>(Wn, Un, shifts, s, wd, l, i, t0, t1, lane, wv);
+            ZSTAMP(pacc2)
+            ++nstage;
+            zchase3<true>(Wn, Un, prm, mbx, shifts, s, wd, l, i, t0, t1, lane, wv, prof != nullptr, cst);
+            ZSTAMP(pacc3)
             for (int e = tid; e < QW * QW; e += kZL) {
                 const int c = e >> 6, r = e & 63;
                 if (r < wd && c < wd) HG(s + r, s + c) = Wn[r * QLD + c];
             }
             __syncthreads();
+            ZSTAMP(pacc2)
             if (s > l) zapply_u<false>(H, n, Wn, Un, s, wd, l, s - l, tid);
             if (e1 < i) zapply_u<true>(H, n, Wn, Un, s, wd, e1 + 1, i - e1, tid);
+            ZSTAMP(pacc4)
         }
     }
     if (info != 0) {
@@ -791,6 +995,19 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
         for (int j = tid; j < info; j += kZL) wout[j] = {qnan, qnan};
     }
     if (tid == 0) info_out[mat] = info;
+    if (prof && tid == 0) {
+        double* pr = prof + mat * 12;
+        pr[0] = (double)pacc0;
+        pr[1] = (double)pacc1;
+        pr[2] = (double)pacc2;
+        pr[3] = (double)pacc3;
+        pr[4] = (double)pacc4;
+        pr[5] = (double)pacc5;
+        pr[6] = (double)nsweep;
+        pr[7] = (double)nstage;
+        for (int x = 0; x < 4; ++x) pr[8 + x] = (double)cst[x];   // chase detail, wave 0: row phase, barrier, column phase, barrier
+    }
+#undef ZSTAMP
 #undef HG
 }
 
@@ -826,12 +1043,12 @@ int zhess_blocked_launch(const void* a, bool in_real, int64_t nmat, int n, int l
     return launch(zhess_blocked_kernel<4, 4>);
 }
 
-int zmsqr_launch(int64_t nmat, int n, double* w, int32_t* info, void* workspace, hipStream_t stream) {
-    const size_t dyn = ((size_t)2 * QW * QLD + QSMALL * QSLD + QM + QSMALL) * sizeof(zq);
+int zmsqr_launch(int64_t nmat, int n, double* w, int32_t* info, void* workspace, double* prof, hipStream_t stream) {
+    const size_t dyn = ((size_t)2 * QW * QLD + QSMALL * QSLD + QM + QSMALL + 6 * QM + 6 * QM) * sizeof(zq);
     EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zmsqr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dyn));
     hipLaunchKernelGGL(zmsqr_kernel, dim3((unsigned)nmat), dim3(kZL), dyn, stream, static_cast<double*>(workspace), n, w,
-                       info);
+                       info, prof);
     EGS_LAUNCH_CHECK();
     return 0;
 }
@@ -845,7 +1062,7 @@ int eig_zlarge_launch(const void* a, bool in_real, int64_t nmat, int n, int lda,
     }
     const int st = zhess_blocked_launch(a, in_real, nmat, n, lda, stride, w, info, workspace, stream);
     if (st) return st;
-    return zmsqr_launch(nmat, n, w, info, workspace, stream);
+    return zmsqr_launch(nmat, n, w, info, workspace, nullptr, stream);
 }
 
 }  // namespace egs

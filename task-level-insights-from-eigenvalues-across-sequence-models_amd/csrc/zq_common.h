@@ -6,9 +6,15 @@
 
 namespace egs {
 
-struct zq {
+// 16-byte aligned: one ds_read_b128 / global_load_dwordx4 per element (the 8-byte aligned form costs the LDS pipe twice
+// the cycles per load).  Every zq* in the kernels points into LDS declared aligned(16), the 256-byte aligned workspace,
+// or the complex128 output.
+struct alignas(16) zq {
     double re, im;
 };
+// select BY VALUE: a ternary on the struct becomes a select between two addresses, which the compiler routes through
+// scratch memory (a round trip to HBM inside the hottest loops)
+__device__ __forceinline__ zq qsel(bool c, zq a, zq b) { return {c ? a.re : b.re, c ? a.im : b.im}; }
 __device__ __forceinline__ zq qadd(zq a, zq b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ zq qsub(zq a, zq b) { return {a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ zq qmul(zq a, zq b) {
@@ -75,10 +81,31 @@ __device__ __forceinline__ void zlarfg2_fast(zq alpha, zq x, double& beta, zq& v
     v2 = qmul(x, sc);
 }
 
-template <class V>
+// sqrt of a complex number on the hardware reciprocal-square-root seed (no IEEE division / square root / hypot):
+// good to a few ulp, for shifts and other quantities that only steer the iteration
+__device__ __forceinline__ zq qsqrt_fast(zq a) {
+    const double m2 = fma(a.re, a.re, a.im * a.im);
+    if (m2 < 1e-300) return {0.0, 0.0};
+    const double m = m2 * fast_rsqrt(m2);
+    const double t = 0.5 * (m + fabs(a.re));
+    const double rs = fast_rsqrt(t);                 // t > 0 because m > 0
+    const double sr = t * rs;
+    const double si = 0.5 * a.im * rs;
+    if (a.re >= 0.0) return {sr, si};
+    return {fabs(si), copysign(sr, a.im)};
+}
+__device__ __forceinline__ zq qdiv_fast(zq a, zq b) {
+    const double r = fast_rcp(fma(b.re, b.re, b.im * b.im));
+    return {fma(a.re, b.re, a.im * b.im) * r, fma(a.im, b.re, -a.re * b.im) * r};
+}
+
+// SHIFTS = true: the eigenvalues are only going to be used as shifts of a multishift sweep -- deflation at 1e-11
+// (one iteration fewer per eigenvalue), no Ahues-Tisseur second test, no search for a start below a small subdiagonal,
+// seed-based arithmetic in the Wilkinson shift.  SHIFTS = false is the xLAHQR iteration that produces final spectra.
+template <class V, bool SHIFTS = false>
 __device__ void zhqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
                           int32_t* __restrict__ info_out) {
-    const double ulp = 2.220446049250313e-16;
+    const double ulp = SHIFTS ? 1e-11 : 2.220446049250313e-16;
     const double safmin = 2.2250738585072014e-308;
     const double smlnum = safmin * ((double)n / ulp);
     const int itmax = 30 * (n > 10 ? n : 10);
@@ -107,7 +134,9 @@ __device__ void zhqr_wave(const V H, const int n, const int lane, double* __rest
                         if (k - 2 >= 0) tst += qabs1(H.at(k - 1, k - 2));
                         if (k + 1 <= n - 1) tst += qabs1(H.at(k + 1, k));
                     }
-                    if (hkk1 <= ulp * tst) {
+                    if (SHIFTS) {
+                        small = hkk1 <= ulp * tst;
+                    } else if (hkk1 <= ulp * tst) {
                         const double hk1k = qabs1(H.at(k - 1, k));
                         const double ab = fmax(hkk1, hk1k), ba = fmin(hkk1, hk1k);
                         const double df = qabs1(qsub(hk1k1, hkk));
@@ -132,6 +161,15 @@ __device__ void zhqr_wave(const V H, const int n, const int lane, double* __rest
                 t = qadd({0.75 * qabs1(H.at(i, i - 1)), 0.0}, H.at(i, i));
             } else if (kdefl % kexsh == 0) {
                 t = qadd({0.75 * qabs1(H.at(l + 1, l)), 0.0}, H.at(l, l));
+            } else if (SHIFTS) {
+                t = H.at(i, i);
+                const zq u2 = qmul(H.at(i - 1, i), H.at(i, i - 1));   // u^2 (the branch of u does not matter below)
+                if (qabs1(u2) != 0.0) {
+                    const zq x = qscale(qsub(H.at(i - 1, i - 1), t), 0.5);
+                    zq y = qsqrt_fast(qadd(qmul(x, x), u2));
+                    if (x.re * y.re + x.im * y.im < 0.0) y = {-y.re, -y.im};
+                    t = qsub(t, qdiv_fast(u2, qadd(x, y)));
+                }
             } else {
                 t = H.at(i, i);
                 const zq u = qmul(qsqrt(H.at(i - 1, i)), qsqrt(H.at(i, i - 1)));
@@ -151,7 +189,7 @@ __device__ void zhqr_wave(const V H, const int n, const int lane, double* __rest
             }
             // ---- start search: lane m in (l, i-1] tests its start vector; default m = l ----
             bool start_ok = false;
-            if (lane > l && lane <= i - 1) {
+            if (!SHIFTS && lane > l && lane <= i - 1) {
                 const int m = lane;
                 const zq h11 = H.at(m, m), h22 = H.at(m + 1, m + 1);
                 zq h11s = qsub(h11, t);
@@ -168,7 +206,8 @@ __device__ void zhqr_wave(const V H, const int n, const int lane, double* __rest
             {
                 const zq h11s = qsub(H.at(m, m), t);
                 const zq h21 = H.at(m + 1, m);
-                const double s = 1.0 / (qabs1(h11s) + qabs1(h21));
+                const double ssum = qabs1(h11s) + qabs1(h21);
+                const double s = SHIFTS ? fast_rcp(fmax(ssum, 1e-300)) : 1.0 / ssum;
                 a0 = qscale(h11s, s);
                 a1 = qscale(h21, s);
             }

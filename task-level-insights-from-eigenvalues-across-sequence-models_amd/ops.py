@@ -104,14 +104,16 @@ def hessenberg_general_batched(a):
     return h, w, info
 
 
-def hseqr_general_batched(h, w, info):
-    """Stage 2 of the level-3 path: multishift QR on the output of hessenberg_general_batched (h is destroyed)."""
+def hseqr_general_batched(h, w, info, profile=False):
+    """Stage 2 of the level-3 path: multishift QR on the output of hessenberg_general_batched (h is destroyed).
+    profile=True also returns the per-matrix phase cycle counts [nmat, 12] (see include/eigspec.h)."""
     _require_cuda(h, "h")
     nmat, n, _ = h.shape
+    prof = torch.zeros((nmat, 12), dtype=torch.float64, device=h.device) if profile else None
     with torch.cuda.device(h.device):
-        check(lib().egs_hseqr_general_batched(_ptr(h), nmat, n, _ptr(w), _ptr(info), _stream()),
+        check(lib().egs_hseqr_general_batched(_ptr(h), nmat, n, _ptr(w), _ptr(info), _ptr(prof), _stream()),
               "egs_hseqr_general_batched")
-    return w, info
+    return (w, info, prof) if profile else (w, info)
 
 
 def hessenberg_batched(a):

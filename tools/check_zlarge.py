@@ -63,5 +63,13 @@ for spec in [x for x in a.time.split(",") if x]:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         h, w, info = ops.hessenberg_general_batched(A); torch.cuda.synchronize(); t1 = time.perf_counter()
         ops.hseqr_general_batched(h, w, info); torch.cuda.synchronize(); t2 = time.perf_counter()
+    h, w, info = ops.hessenberg_general_batched(A)
+    _, _, prof = ops.hseqr_general_batched(h, w, info, profile=True)
+    torch.cuda.synchronize()
+    pm = prof.cpu().numpy().mean(axis=0)
+    names = ["scan", "small_qr", "win_io", "chase", "apply_u", "base_chase"]
     print(json.dumps({"check": "time", "n": n, "nmat": m, "hess_ms": (t1 - t0) * 1e3, "qr_ms": (t2 - t1) * 1e3,
-                      "unconverged": int((info != 0).sum())}), flush=True)
+                      "unconverged": int((info != 0).sum()),
+                      "mean_kcycles": {k: round(float(v) / 1e3, 1) for k, v in zip(names, pm[:6])},
+                      "sweeps": float(pm[6]), "windows": float(pm[7]),
+                      "chase_split_kcycles": [round(float(v) / 1e3, 1) for v in pm[8:12]]}), flush=True)
