@@ -96,7 +96,7 @@ def test_eig_empty_batch_and_bad_args(gpu_ops):
     w, info = gpu_ops.eig_general_batched(torch.zeros((0, 8, 8), dtype=torch.float64, device="cuda"))
     assert w.shape == (0, 8) and info.shape == (0,)
     with pytest.raises(TypeError):
-        gpu_ops.eig_general_batched(torch.zeros((2, 4, 4), dtype=torch.float32, device="cuda"))
+        gpu_ops.eig_general_batched(torch.zeros((2, 4, 4), dtype=torch.int64, device="cuda"))
     with pytest.raises(ValueError):
         gpu_ops.eig_general_batched(torch.zeros((2, 4, 5), dtype=torch.float64, device="cuda"))
 
