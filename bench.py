@@ -272,7 +272,7 @@ def stream_rooflines(ops, device):
     b = (torch.rand((2 * dqk,), generator=g, device=device) * 2 - 1) / np.sqrt(D)
     ms = med(lambda: ops.linattn_eta(x, w, b, dqk, 1), reps=3)
     tf = B * L * 2.0 * D * 2 * dqk / ms / 1e9
-    out.append({"kernel": "qk_proj_mfma_kernel + linattn_chunksum/scan + eta_finalize",
+    out.append({"kernel": "qk_proj_mfma2_kernel + linattn_scan_kernel + eta_finalize_kernel",
                 "workload": "C4 / 8 GPUs: linear attention eta, B=512, L=4096, D=128, d_qk=128, H=1",
                 "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "ms": ms,
                 "note": "fp32 MFMA (= fp32 vector peak); whole op incl. the fp64 scan",
@@ -285,7 +285,7 @@ def stream_rooflines(ops, device):
     b = (torch.rand((2 * dqk,), generator=g, device=device) * 2 - 1) / np.sqrt(D)
     ms = med(lambda: ops.softmax_eta(x, w, b, dqk, 1), reps=3)
     tf = (2 * B * L * (L + 1) / 2 * dqk * 2 + B * L * 2.0 * D * 2 * dqk) / ms / 1e9
-    out.append({"kernel": "qk_proj_mfma_kernel + softmax_nu_mfma_kernel + eta_finalize",
+    out.append({"kernel": "qk_proj_mfma2_kernel + softmax_nu_mfma_kernel + eta_finalize_kernel",
                 "workload": "MQAR analysis batch: softmax attention eta, B=4096, L=512, D=128, d_qk=64, H=1",
                 "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "ms": ms,
                 "note": "fp32 MFMA; algorithmic flops = projection + 2 passes of the causal q.k tiles; the fp64 "
@@ -302,6 +302,50 @@ def stream_rooflines(ops, device):
                 "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "ms": ms,
                 "note": "fp32 MFMA, chunked recurrence; algorithmic flops = 4 d C per token (state update + readout); "
                         "the kernel executes 1.4x that (intra-chunk tiles), matrix pipe 83 % busy (profiles/r01_blocks.json)"})
+    del qk, v
+    # K5 at config C5: 768 HiPPO-DPLR 256 x 256 complex128 matrices (6 layers x 128 feature columns, per-column steps):
+    # fused DPLR build, blocked Hessenberg on the fp64 matrix cores, windowed multishift QR -- the two stages timed apart
+    import oracle as O
+    n, h = 256, 768
+    lam, p, _, _, _ = O.make_dplr_hippo(n)
+    rng = np.random.default_rng(256)
+    ls = rng.uniform(np.log(1e-3), np.log(1e-1), h)
+    dd = lambda z: torch.from_numpy(np.ascontiguousarray(z)).to(device)
+    ab = ops.s4_dplr_build(dd(np.tile(lam.real, (h, 1))), dd(np.tile(lam.imag, (h, 1))), dd(np.tile(p, (h, 1))), dd(ls))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    hs, qr = [], []
+    unconv = 0
+    for rep in range(4):
+        ev[0].record()
+        hh, ww, ii = ops.hessenberg_general_batched(ab)
+        ev[1].record()
+        ops.hseqr_general_batched(hh, ww, ii)
+        ev[2].record()
+        ev[2].synchronize()
+        if rep:
+            hs.append(ev[0].elapsed_time(ev[1]))
+            qr.append(ev[1].elapsed_time(ev[2]))
+        unconv = int((ii != 0).sum().item())
+    hs_ms, qr_ms = float(np.median(hs)), float(np.median(qr))
+    flops = 4.0 * (40.0 / 3.0) * n ** 3 * h            # (40/3) n^3 real-matrix flops, x4 for complex
+    tf = flops / ((hs_ms + qr_ms) * 1e-3) / 1e12
+    tf_h = 4.0 * (10.0 / 3.0) * n ** 3 * h / (hs_ms * 1e-3) / 1e12
+    tf_q = 4.0 * 10.0 * n ** 3 * h / (qr_ms * 1e-3) / 1e12
+    tr = torch.diagonal(ab, dim1=1, dim2=2).sum(dim=1)
+    trerr = float(((ww.sum(dim=1) - tr).abs() / torch.linalg.matrix_norm(ab)).max().item())
+    out.append({"kernel": "zhess_blocked_kernel<16,2> + zmsqr_kernel",
+                "workload": "C5: S4 HiPPO-DPLR d_state=256, 6 layers x 128 columns = 768 complex128 256x256 matrices",
+                "bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                "ms": hs_ms + qr_ms, "spectra_per_s": h / ((hs_ms + qr_ms) * 1e-3), "unconverged": unconv,
+                "max_rel_trace_error": trerr,
+                "stages": {"zhess_blocked_kernel": {"ms": hs_ms, "achieved_tflops": tf_h, "frac": tf_h / FP64_PEAK_TFLOPS,
+                                                    # its bound: one matrix-vector product with the trailing matrix per
+                                                    # column = 16 n^3 / 3 bytes per matrix that no blocking removes
+                                                    "hbm_gbs_algorithmic": 16.0 * n ** 3 / 3.0 * h / (hs_ms * 1e-3) / 1e9,
+                                                    "hbm_frac": 16.0 * n ** 3 / 3.0 * h / (hs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                           "zmsqr_kernel": {"ms": qr_ms, "achieved_tflops": tf_q, "frac": tf_q / FP64_PEAK_TFLOPS}},
+                "note": "fp64 (matrix = vector peak); algorithmic flops 4 x (40/3) n^3 per matrix (Hessenberg 4 x (10/3) "
+                        "n^3, QR 4 x 10 n^3); HIP events on the launch stream, median of 3"})
     return out
 
 
