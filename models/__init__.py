@@ -16,7 +16,7 @@ Mamba, Transformer = _pkg.Mamba, _pkg.Transformer
 
 def __getattr__(name):
     if name in ("init_LRU", "init_S4", "init_S5", "LRU", "S4", "S5SSM", "BatchClassificationModel"):
-        raise ImportError(f"models.{name} is the reference's JAX/flax code path (jax is not installed here); the "
-                          "analysis initialises SSM parameters with analysis.eval_eig.init_layers_ssm_numpy "
-                          "(conf_args['ssm_init'] = 'numpy')")
+        raise ImportError(f"models.{name} is the reference's JAX/flax code path (jax / flax are not installed here). For the "
+                          "eigenvalue analysis set `ssm_init: numpy` in the analysis YAML (NumPy draws of log_step / nu / "
+                          "theta from the reference's distributions; see analysis.eval_eig.init_layers_ssm_numpy)")
     raise AttributeError(name)

@@ -12,6 +12,7 @@ Differences that are deliberate and documented in DESIGN.md:
 """
 import os
 import tempfile
+import warnings
 
 import numpy as np
 import torch
@@ -395,20 +396,54 @@ def _torch_family(layer_type, model_config, pseudo_lti):
     return None
 
 
-def _spectra_pass(model, layer_type, loader, family, num_layers):
+def _has_live_dropout(model):
+    return model.training and any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in model.modules())
+
+
+def _spectra_pass(model, layer_type, loader, family, num_layers, gather=True):
     """One pass of eval_eig.py:500-564 / :574-663: encoder, then block i followed by the spectra of block i computed
-    from block i's OUTPUT (quirk Q1).  The batch is sharded across ranks; returns the full (B, T, H, layers) tensor."""
+    from block i's OUTPUT (quirk Q1).  The batch is sharded across ranks (contiguous slabs, no data-path collective);
+    with gather=True the full (B, T, H, layers) tensor is returned on every rank (ONE all_gather), otherwise this
+    rank's slab and its [lo, hi) range.
+
+    The reference's "init" pass runs in train mode (quirk Q8): with live dropout the masks come out of one RNG stream
+    over the whole batch, so a sharded pass could not reproduce the single-GPU eig_init.  That pass is therefore run
+    unsharded on every rank (identical results, no exchange); everything else is sharded."""
     layers = get_layers(layer_type, model)
     X, _, _ = next(iter(loader))
     n_total = X.shape[0]
-    lo, hi = egs_dist.shard_range(n_total)
-    x = model.encoder(X[lo:hi].to("cuda"))
-    per_layer = []
-    for i in range(num_layers):
-        x = layers[i](x)
-        per_layer.append(family(x, layers[i]))
-    local = torch.stack(per_layer, dim=-1)                              # (B_local, T, H, layers)
-    return egs_dist.all_gather_slabs(local, n_total)
+    full = _has_live_dropout(model)
+    lo, hi = (0, n_total) if full else egs_dist.shard_range(n_total)
+    with torch.no_grad():
+        x = model.encoder(X[lo:hi].to("cuda"))
+        per_layer = []
+        for i in range(num_layers):
+            x = layers[i](x)
+            per_layer.append(family(x, layers[i]))
+        local = torch.stack(per_layer, dim=-1)                          # (B_local, T, H, layers)
+    if full:
+        if gather:
+            return local
+        lo, hi = egs_dist.shard_range(n_total)
+        return local[lo:hi], (lo, hi, n_total)
+    if gather:
+        return egs_dist.all_gather_slabs(local, n_total)
+    return local, (lo, hi, n_total)
+
+
+def _hist_exchange(eig_local, rng, thresholds, num_layers, num_heads, batch_size, transform):
+    """Histogram-only exchange: percentages of this rank's batch rows, completed by one
+    all_reduce(sum) of the (bins, B, H, layers) array -- the spectra themselves never leave their GPU."""
+    lo, hi, n_total = rng
+    nb = len(np.asarray(thresholds).flatten()) + 1
+    full = torch.zeros((nb, n_total, num_heads, num_layers), dtype=torch.float64, device="cuda")
+    if hi > lo:
+        full[:, lo:hi] = _hist(eig_local, thresholds, transform)
+    full = egs_dist.all_reduce_slab_sum(full)
+    if tuple(full.shape[1:]) != (batch_size, num_heads, num_layers):
+        raise ValueError("could not broadcast input array from shape {0} into shape {1}".format(
+            tuple(full.shape[1:]), (batch_size, num_heads, num_layers)))
+    return full.cpu().numpy()
 
 
 def eval_eig(args, conf_args, wandb_config, data_config, loader, path_file, perf, model_classes=None):
@@ -425,6 +460,10 @@ def eval_eig(args, conf_args, wandb_config, data_config, loader, path_file, perf
     path = path_file if os.path.isabs(path_file) else os.path.abspath(os.getcwd()) + "/" + path_file
     layer_type = model_config.pop("layer")                               # mutates the caller's dict (eval_eig.py:479)
     ssm_dtype = conf_args.get("ssm_dtype", "complex128")
+    # started under a distributed launcher (torchrun launch.py ...)?  Then this call is one rank of the job: join the
+    # process group here, because the reference's caller never does (launch.py:176, :183).
+    rank, _world = egs_dist.bootstrap()
+    hist_only = conf_args.get("exchange", "spectra") == "histogram" and _world > 1
 
     if layer_type in ["mamba", "transformer"]:
         num_heads = model_config["num_heads"]
@@ -434,36 +473,66 @@ def eval_eig(args, conf_args, wandb_config, data_config, loader, path_file, perf
             model_classes = {"mamba": _models.Mamba, "transformer": _models.Transformer}
         model = model_classes[layer_type](model_config).to("cuda")
         family = _torch_family(layer_type, model_config, pseudo_lti)
-        eig_init_t = _spectra_pass(model, layer_type, loader, family, num_layers)     # train mode (quirk Q8)
-        model.load_state_dict(torch.load(path, weights_only=True))
-        model.eval()
-        eig_t = _spectra_pass(model, layer_type, loader, family, num_layers)
-
         thresholds_radius = np.array(THRESHOLDS_RADIUS)
         thresholds_phase = np.array(THRESHOLDS_PHASE)
         if layer_type == "mamba":            # radius / phase of the (real) lambdas (eval_eig.py:603-618)
             rad_tr, ph_tr = "radius", "phase"
         else:                                # eta as is; phase histograms of 0*eta (quirk Q13, eval_eig.py:665-674)
             rad_tr, ph_tr = "value", "zero"
-        percentage_init = threshold_analysis(eig_init_t, thresholds_radius, num_layers, num_heads, batch_size, rad_tr)
-        percentage = threshold_analysis(eig_t, thresholds_radius, num_layers, num_heads, batch_size, rad_tr)
-        percentage_phase_init = threshold_analysis(eig_init_t, thresholds_phase, num_layers, num_heads, batch_size, ph_tr)
-        percentage_phase = threshold_analysis(eig_t, thresholds_phase, num_layers, num_heads, batch_size, ph_tr)
+        if hist_only:
+            # spectra stay sharded (the returned eig / eig_init are this rank's batch rows); one tiny all_reduce per histogram
+            eig_init_t, rng_i = _spectra_pass(model, layer_type, loader, family, num_layers, gather=False)   # train mode (Q8)
+            model.load_state_dict(torch.load(path, weights_only=True))
+            model.eval()
+            eig_t, rng_t = _spectra_pass(model, layer_type, loader, family, num_layers, gather=False)
+            percentage_init = _hist_exchange(eig_init_t, rng_i, thresholds_radius, num_layers, num_heads, batch_size, rad_tr)
+            percentage = _hist_exchange(eig_t, rng_t, thresholds_radius, num_layers, num_heads, batch_size, rad_tr)
+            percentage_phase_init = _hist_exchange(eig_init_t, rng_i, thresholds_phase, num_layers, num_heads, batch_size, ph_tr)
+            percentage_phase = _hist_exchange(eig_t, rng_t, thresholds_phase, num_layers, num_heads, batch_size, ph_tr)
+        else:
+            eig_init_t = _spectra_pass(model, layer_type, loader, family, num_layers)     # train mode (quirk Q8)
+            model.load_state_dict(torch.load(path, weights_only=True))
+            model.eval()
+            eig_t = _spectra_pass(model, layer_type, loader, family, num_layers)
+            percentage_init = threshold_analysis(eig_init_t, thresholds_radius, num_layers, num_heads, batch_size, rad_tr)
+            percentage = threshold_analysis(eig_t, thresholds_radius, num_layers, num_heads, batch_size, rad_tr)
+            percentage_phase_init = threshold_analysis(eig_init_t, thresholds_phase, num_layers, num_heads, batch_size, ph_tr)
+            percentage_phase = threshold_analysis(eig_t, thresholds_phase, num_layers, num_heads, batch_size, ph_tr)
         percentage_init_mean = np.mean(percentage_init, axis=1)
         percentage_init_std = np.std(percentage_init, axis=1)
         percentage_mean = np.mean(percentage, axis=1)
         percentage_std = np.std(percentage, axis=1)
         eig, eig_init = eig_t.cpu().numpy(), eig_init_t.cpu().numpy()    # the one device->host copy of the spectra
-        create_file_percentage(thresholds_radius, percentage, percentage_init, percentage_mean, percentage_init_mean,
-                               percentage_std, percentage_init_std)
+        if rank == 0:                                                    # one writer of ./percentage_file.txt
+            create_file_percentage(thresholds_radius, percentage, percentage_init, percentage_mean, percentage_init_mean,
+                                   percentage_std, percentage_init_std)
 
     elif layer_type in ["lru", "s4", "s5"]:
         SEQ_LEN = model_config["seq_len"]
         dim_idx = 1                                                      # eval_eig.py:689 (quirk Q9)
-        if conf_args.get("ssm_init", "jax") == "numpy":
+        ssm_init = conf_args.get("ssm_init", "jax")
+        if ssm_init not in ("jax", "numpy"):
+            raise ValueError("analysis config key 'ssm_init' must be 'jax' or 'numpy', got {0!r}".format(ssm_init))
+        if ssm_init == "numpy":
+            note = ("ssm_init: numpy -- the random parts of the {0} initialisation (log_step / nu / theta) were drawn "
+                    "with NumPy's generator from the reference's distributions, NOT from JAX's PRNG stream: eig_init, "
+                    "percentage_init and percentage_phase_init agree with the reference in distribution, not "
+                    "bitwise".format(layer_type))
+            warnings.warn(note, stacklevel=2)
+            args["analysis_notes"] = [note]                              # lands in used_config.yaml next to the arrays
             init_layers = init_layers_ssm_numpy(layer_type, seed, model_config)
         else:
             if model_classes is None:
+                try:
+                    import jax  # noqa: F401
+                    import flax  # noqa: F401
+                except ImportError as exc:
+                    raise RuntimeError(
+                        "analysis config key 'ssm_init' (default 'jax'): the reference initialises the {0} parameters "
+                        "with jax + flax (analysis/eval_eig.py:207-239), which are not installed in this environment. "
+                        "Either install jax==0.4.25 / flax==0.8.1, or set `ssm_init: numpy` in the analysis YAML to draw "
+                        "the random parts (log_step, nu, theta) with NumPy -- same distributions, different PRNG stream, "
+                        "so the *_init artefacts are then not bit-identical to the reference's".format(layer_type)) from exc
                 import models as _models
                 model_classes = {"lru": _models.init_LRU, "s4": _models.init_S4, "s5": _models.init_S5}
             init_layers = get_init_layers_ssm(seed, data_config, train_config, model_config, SEQ_LEN,
@@ -484,12 +553,12 @@ def eval_eig(args, conf_args, wandb_config, data_config, loader, path_file, perf
         percentage_phase_init = threshold_analysis_ssm(eig_init, thresholds_phase, num_layers, "phase")
         percentage_phase = threshold_analysis_ssm(eig, thresholds_phase, num_layers, "phase")
         percentage_init_mean = percentage_init_std = percentage_mean = percentage_std = 0      # quirk Q14
-        create_file_percentage_ssm(thresholds_radius, thresholds_phase, percentage, percentage_init, percentage_phase,
-                                   percentage_phase_init)
+        if rank == 0:
+            create_file_percentage_ssm(thresholds_radius, thresholds_phase, percentage, percentage_init, percentage_phase,
+                                       percentage_phase_init)
     else:
         raise RuntimeError("{0} is not a valid model option".format(layer_type))
 
-    rank, _ = egs_dist.world()
     if rank == 0:
         _save_artifacts(args, conf_args, wandb_config, data_config, model_config, train_config, perf,
                         [eig, eig_init, percentage, percentage_init, percentage_phase, percentage_phase_init,

@@ -22,10 +22,22 @@ _EXT_NDARRAY, _EXT_COMPLEX, _EXT_NPSCALAR = 1, 2, 3
 _CHUNK_KEY = "__msgpack_chunked_array__"
 
 
+def _dtype(name):
+    """NumPy dtype of a flax-serialised array.  bfloat16 is not a NumPy type: it needs ml_dtypes (what JAX itself uses)."""
+    if name == "bfloat16":
+        try:
+            import ml_dtypes
+        except ImportError as exc:
+            raise NotImplementedError("this checkpoint stores bfloat16 arrays; decoding them needs the ml_dtypes "
+                                      "package (not installed here)") from exc
+        return np.dtype(ml_dtypes.bfloat16)
+    return np.dtype(name)
+
+
 def _ndarray_from_bytes(data):
     import msgpack
     shape, dtype_name, buf = msgpack.unpackb(data, raw=False)
-    return np.frombuffer(buf, dtype=np.dtype(dtype_name)).reshape(shape).copy()
+    return np.frombuffer(buf, dtype=_dtype(dtype_name)).reshape(shape).copy()
 
 
 def _ext_hook(code, data):
@@ -45,7 +57,10 @@ def _unchunk(tree):
         if tree.get(_CHUNK_KEY):
             chunks = tree["chunks"]
             flat = np.concatenate([np.asarray(chunks[str(i)]).reshape(-1) for i in range(len(chunks))])
-            return flat.reshape(tuple(tree["shape"]))
+            shape = tree["shape"]
+            if isinstance(shape, dict):          # flax stores tuples as {"0": n0, "1": n1, ...} (_tuple_to_dict)
+                shape = [shape[str(i)] for i in range(len(shape))]
+            return flat.reshape(tuple(int(v) for v in shape))
         return {k: _unchunk(v) for k, v in tree.items()}
     return tree
 

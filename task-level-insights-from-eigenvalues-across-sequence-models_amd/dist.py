@@ -5,8 +5,32 @@ per-rank slabs with no data-path collective; the only exchange is ONE all-gather
 (RCCL over xGMI when the process group's backend is "nccl"; gloo on CPU in the tests).  The reference has no
 distributed code at all (single process, device "cuda": launch.py:63-66, analysis/eval_eig.py:497).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def bootstrap():
+    """Join the job's process group when this process was started by a distributed launcher (``torchrun launch.py ...``:
+    WORLD_SIZE / RANK / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in the environment) and nobody has initialised one yet.
+    The reference's caller (launch.py:176, :183) knows nothing about ranks, so the drop-in entry point does this itself:
+    one process per GPU, device = LOCAL_RANK, backend "nccl" (= RCCL over xGMI on ROCm).  EGS_DIST_BACKEND=gloo selects
+    the CPU backend (tests; several ranks sharing one GPU).  Returns (rank, world_size)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if dist.is_available() and not dist.is_initialized() and ws > 1:
+        backend = os.environ.get("EGS_DIST_BACKEND", "nccl")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")), world_size=ws)
+    return world()
+
+
+def _host_staged(group=None):
+    """gloo moves host memory: device slabs are staged through the host around the collective."""
+    return dist.get_backend(group) == "gloo"
 
 
 def world():
@@ -38,9 +62,25 @@ def all_gather_slabs(local, n_total, group=None):
         filler = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, filler], dim=0)
     local = local.contiguous()
+    device = local.device
+    if local.is_cuda and _host_staged(group):
+        local = local.cpu()
     out = torch.empty((world_size * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if local.is_complex():
         dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(local), group=group)
     else:
         dist.all_gather_into_tensor(out, local, group=group)
-    return out[:n_total]
+    return out[:n_total].to(device)
+
+
+def all_reduce_slab_sum(full, group=None):
+    """The histogram-only exchange of SURVEY.md 8(e): every rank has filled ITS batch rows of `full` (zeros elsewhere),
+    one all_reduce(sum) completes it on every rank.  Bit-exact: each element receives exactly one non-zero term."""
+    rank, world_size = world()
+    if world_size == 1:
+        return full
+    device = full.device
+    buf = full.cpu() if (full.is_cuda and _host_staged(group)) else full
+    buf = buf.contiguous()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf.to(device)

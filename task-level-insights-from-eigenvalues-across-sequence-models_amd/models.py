@@ -166,8 +166,7 @@ class LayerNorm(nn.LayerNorm):
     def forward(self, x):
         if len(self.normalized_shape) != 1 or self.normalized_shape[0] > 1024:
             return super().forward(x)
-        with torch.no_grad():
-            return ops.layer_norm(x, self.weight, self.bias, self.eps)
+        return _hip(lambda a, w, b: ops.layer_norm(a, w, b, self.eps), x, self.weight, self.bias)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -175,6 +174,30 @@ class LayerNorm(nn.LayerNorm):
 # ---------------------------------------------------------------------------------------------------------------
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
+
+
+class _ForwardOnly(torch.autograd.Function):
+    """The HIP mixers have no backward.  When autograd is recording and an input requires grad, the op is put on the
+    tape with a backward that RAISES, so that ``loss.backward()`` through these models (they carry the names the
+    reference's train.py imports) fails loudly instead of silently training only the layers behind the last mixer."""
+
+    @staticmethod
+    def forward(ctx, fn, *inputs):
+        with torch.no_grad():
+            return fn(*inputs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError("these models are forward-only (eigenvalue analysis): the HIP token mixers, LayerNorm "
+                                  "and conv have no backward pass; train with the reference's models")
+
+
+def _hip(fn, *tensors):
+    """Run a HIP op on `tensors` outside autograd, keeping a raising backward node when gradients were requested."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        return _ForwardOnly.apply(fn, *tensors)
+    with torch.no_grad():
+        return fn(*tensors)
 
 
 class SelfLinAttention(nn.Module):
@@ -186,9 +209,8 @@ class SelfLinAttention(nn.Module):
 
     def forward(self, qk, v):
         b, l, h, dv = v.shape
-        with torch.no_grad():
-            y = ops.linear_recurrence_fwd(_f32(qk[:, :, 0]), _f32(qk[:, :, 1]), _f32(v).reshape(b, l, h * dv), phi=True,
-                                          normalise=True)
+        y = _hip(lambda qk_, v_: ops.linear_recurrence_fwd(_f32(qk_[:, :, 0]), _f32(qk_[:, :, 1]),
+                                                             _f32(v_).reshape(b, l, h * dv), phi=True, normalise=True), qk, v)
         return self.dropout(y.view(b, l, h, dv))
 
 
@@ -207,8 +229,8 @@ class SelfAttention(nn.Module):
             scores = torch.einsum("bthd,bshd->bhts", q, k * (1.0 / math.sqrt(q.shape[-1])))
             scores = scores + torch.triu(torch.full((l, l), -10000.0, device=scores.device), 1).to(scores.dtype)
             return torch.einsum("bhts,bshd->bthd", self.dropout(torch.softmax(scores, dim=-1, dtype=v.dtype)), v)
-        with torch.no_grad():
-            y = ops.softmax_attention_fwd(_f32(qk[:, :, 0]), _f32(qk[:, :, 1]), _f32(v).reshape(b, l, h * dv))
+        y = _hip(lambda qk_, v_: ops.softmax_attention_fwd(_f32(qk_[:, :, 0]), _f32(qk_[:, :, 1]),
+                                                             _f32(v_).reshape(b, l, h * dv)), qk, v)
         return y.view(b, l, h, dv)
 
 
@@ -264,11 +286,12 @@ class SelfNormAttention(nn.Module):
     def forward(self, qk, v, n):
         b, l, h, dv = v.shape
         scale = 1.0 / math.sqrt(qk.shape[-1]) if self.scale_B else 1.0
-        with torch.no_grad():
-            raw = n + self.offset if self.offset is not None else n
+        def run(qk_, v_, n_, off_):
+            raw = n_ + off_ if off_ is not None else n_
             w = torch.exp(-self.norm_fn(_f32(raw)))
-            y = ops.linear_recurrence_fwd(_f32(qk[:, :, 0]), _f32(qk[:, :, 1]), _f32(v).reshape(b, l, h * dv), w=w,
-                                          phi=(self.approx_name == "elu"), k_scale=scale)
+            return ops.linear_recurrence_fwd(_f32(qk_[:, :, 0]), _f32(qk_[:, :, 1]), _f32(v_).reshape(b, l, h * dv), w=w,
+                                             phi=(self.approx_name == "elu"), k_scale=scale)
+        y = _hip(run, qk, v, n, self.offset)
         return self.dropout(y.view(b, l, h, dv))
 
 
@@ -280,8 +303,7 @@ def _depthwise_causal(conv, act, x, seqlen):
     channel-last activations (``act`` is the module's nn.SiLU; kernels wider than 8 taps fall outside the ABI)."""
     if conv.kernel_size[0] > 8:
         raise NotImplementedError("depthwise conv kernels wider than 8 taps are not supported")
-    with torch.no_grad():
-        return ops.causal_conv1d_silu(x, conv.weight, conv.bias)
+    return _hip(ops.causal_conv1d_silu, x, conv.weight, conv.bias)
 
 
 class MHA(nn.Module):
@@ -529,15 +551,21 @@ class _SSDBase(nn.Module):
         mamba_ssm's mamba_chunk_scan_combined evaluates chunk-wise; z = None, no dt_softplus, default dt_limit)."""
         if self.learnable_init_states:
             raise NotImplementedError("learnable_init_states is not supported by the HIP scan")
-        if self.dt_limit != (0.0, float("inf")):
-            vscale = vscale.clamp(self.dt_limit[0], self.dt_limit[1])
         b, l, _ = x.shape
-        with torch.no_grad():
-            y = ops.linear_recurrence_fwd(_f32(Cm).unflatten(-1, (self.ngroups, self.d_state)),
-                                          _f32(Bm).unflatten(-1, (self.ngroups, self.d_state)), _f32(x),
-                                          decay=decay, vscale=vscale, skip=_f32(self.D).repeat_interleave(self.headdim),
-                                          cols_per_decay=self.headdim)
-        return y
+
+        def run(x_, decay_, vscale_, b_, c_, d_):
+            return ops.linear_recurrence_fwd(_f32(c_).unflatten(-1, (self.ngroups, self.d_state)),
+                                             _f32(b_).unflatten(-1, (self.ngroups, self.d_state)), _f32(x_),
+                                             decay=decay_, vscale=vscale_, skip=_f32(d_).repeat_interleave(self.headdim),
+                                             cols_per_decay=self.headdim)
+        return _hip(run, x, decay, vscale, Bm, Cm, self.D)
+
+    def _clamp_dt(self, dt):
+        """mamba_chunk_scan_combined clamps dt to dt_limit BEFORE it forms exp(dt A) and dt x: decay and input scale both
+        see the clamped value."""
+        if self.dt_limit != (0.0, float("inf")):
+            return dt.clamp(self.dt_limit[0], self.dt_limit[1])
+        return dt
 
 
 class SSD(_SSDBase):
@@ -553,9 +581,9 @@ class SSD(_SSDBase):
     def forward(self, u, seq_idx=None):
         x, Bm, Cm, dt = self._split(u, self.nheads)
         A = -torch.exp(self.A_log)
-        with torch.no_grad():
-            decay = torch.exp(_f32(dt) * _f32(A))                    # the eigenvalue lambda_t of eval_eig.py:176-190
-        return self.out_proj(self._scan(x, decay, _f32(dt), Bm, Cm))
+        dt = self._clamp_dt(_f32(dt))
+        decay = torch.exp(dt * _f32(A))                              # the eigenvalue lambda_t of eval_eig.py:176-190
+        return self.out_proj(self._scan(x, decay, dt, Bm, Cm))
 
 
 class SSD_LTI(_SSDBase):
@@ -575,10 +603,10 @@ class SSD_LTI(_SSDBase):
         beta = self.beta.expand(batch, seqlen, -1)
         A = -F.softplus(self.A)
         Bm = dt.repeat_interleave(self.khead_dim, dim=-1) * Bm       # (B, L, d_state)
-        with torch.no_grad():
-            decay = torch.exp(_f32(beta) * _f32(A)).contiguous()
+        beta = self._clamp_dt(_f32(beta)).contiguous()
+        decay = torch.exp(beta * _f32(A)).contiguous()
         # the reference reshapes B, C as "b l (n g) -> b l n g" with n = ngroups (:283-284): ngroups leading
-        return self.out_proj(self._scan(x, decay, _f32(beta).contiguous(), Bm, Cm))
+        return self.out_proj(self._scan(x, decay, beta, Bm, Cm))
 
 
 class MambaBlock(nn.Module):

@@ -29,10 +29,12 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _workspace(device, nbytes):
-    """Grow-only scratch buffer per device (the C ABI never allocates)."""
+def _workspace(device, nbytes, tag="scratch"):
+    """Grow-only scratch buffer per (device, stream, purpose) -- the C ABI never allocates.  Keyed by the CURRENT
+    stream: two streams (or two host threads driving their own streams) never share scratch, and a buffer is only ever
+    released to torch's caching allocator from the stream that used it, which keeps the release stream-ordered."""
     nbytes = max(int(nbytes), 256)
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         _workspaces[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -135,7 +137,7 @@ def hseqr_batched(h):
     w = torch.empty((nmat, n), dtype=torch.complex128, device=h.device)
     info = torch.empty((nmat,), dtype=torch.int32, device=h.device)
     with torch.cuda.device(h.device):
-        queue = _workspace(h.device, 256)
+        queue = _workspace(h.device, 256, tag="hqr-queue")      # its own allocation: never aliases an op's scratch
         check(lib().egs_hseqr_batched(_ptr(h), nmat, n, _ptr(w), _ptr(info), _ptr(queue), _stream()), "egs_hseqr_batched")
     return w, info
 

@@ -413,3 +413,39 @@ def test_layer_norm_vs_torch(gpu_ops, shape):
     close(got, want.cpu().numpy(), rtol=3e-6, atol=2e-6)
     close(plain, want_plain.cpu().numpy(), rtol=3e-6, atol=2e-6)
     close(strided, want_strided.cpu().numpy(), rtol=3e-6, atol=2e-6)
+
+
+def test_backward_through_the_hip_mixers_raises(pkg, gpu_ops):
+    """The drop-in models are forward-only.  They carry the names the reference's train.py imports, so a backward pass
+    through them must fail loudly instead of silently detaching everything in front of the last HIP op."""
+    ln = pkg.models.LayerNorm(16).cuda()
+    x = torch.randn(4, 16, device="cuda", requires_grad=True)
+    y = ln(x)
+    assert y.requires_grad and y.grad_fn is not None
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        y.sum().backward()
+    with torch.no_grad():
+        assert not ln(x).requires_grad
+    mix = pkg.models.SelfLinAttention().cuda()
+    qk = torch.randn(2, 8, 2, 1, 4, device="cuda", requires_grad=True)
+    v = torch.randn(2, 8, 1, 8, device="cuda")
+    out = mix(qk, v)
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
+
+
+def test_ssd_dt_limit_clamps_decay_and_input_scale(pkg, gpu_ops):
+    """mamba_chunk_scan_combined clamps dt to dt_limit before forming exp(dt A) and dt x (models/mamba.py:121, :149):
+    a forward with dt_limit must equal the forward of an unlimited mixer fed the clamped dt."""
+    torch.manual_seed(3)
+    a = pkg.models.SSD(32, d_state=8, d_conv=4, expand=1, headdim=8, dt_limit=(0.02, 0.05)).cuda().eval()
+    b = pkg.models.SSD(32, d_state=8, d_conv=4, expand=1, headdim=8).cuda().eval()
+    b.load_state_dict(a.state_dict())
+    u = torch.randn(2, 16, 32, device="cuda")
+    with torch.no_grad():
+        ya = a(u)
+        x, Bm, Cm, dt = b._split(u, b.nheads)
+        dtc = dt.float().clamp(0.02, 0.05)
+        yb = b.out_proj(b._scan(x, torch.exp(dtc * -torch.exp(b.A_log.float())), dtc, Bm, Cm))
+    assert (dt.float() != dtc).any()                       # the limit is active on this input
+    torch.testing.assert_close(ya, yb, rtol=1e-6, atol=1e-6)

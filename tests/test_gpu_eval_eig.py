@@ -221,6 +221,36 @@ def test_eval_eig_ssm_families(pkg, tmp_path, monkeypatch, kind):
     assert saved.shape == () and saved == 0                                    # quirk Q14
 
 
+def test_eval_eig_ssm_init_key_is_explicit(pkg, tmp_path, monkeypatch):
+    """Without jax / flax the default `ssm_init: jax` must stop with a message that names the analysis-YAML key (not an
+    ImportError from deep inside a shim); `ssm_init: numpy` works, warns, and records the substitution in
+    used_config.yaml next to the arrays it affects."""
+    try:
+        import jax  # noqa: F401
+        import flax  # noqa: F401
+        pytest.skip("jax + flax are installed: the reference's own init path is available")
+    except ImportError:
+        pass
+    monkeypatch.chdir(tmp_path)
+    ev = sys.modules[pkg.__name__ + ".analysis.eval_eig"]
+    args = _args("lru", state_dim=16, hidden_dim=4, r_min=0.9, r_max=0.99)
+    trained = ev.init_layers_ssm_numpy("lru", 77, args["model"])
+    np.savez(tmp_path / "ckpt.npz", **{f"encoder/layers_{i}/seq/{k}": v for i, layer in enumerate(trained)
+                                       for k, v in layer.items()})
+    with pytest.raises(RuntimeError, match="ssm_init"):
+        pkg.eval_eig(copy.deepcopy(args), {"batch_size": B}, None, None, None, str(tmp_path / "ckpt.npz"), 0.9)
+    with pytest.raises(ValueError, match="ssm_init"):
+        pkg.eval_eig(copy.deepcopy(args), {"batch_size": B, "ssm_init": "threefry"}, None, None, None,
+                     str(tmp_path / "ckpt.npz"), 0.9)
+    with pytest.warns(UserWarning, match="ssm_init: numpy"):
+        pkg.eval_eig(copy.deepcopy(args), {"batch_size": B, "ssm_init": "numpy"}, None, None, None,
+                     str(tmp_path / "ckpt.npz"), 0.9)
+    import yaml
+    used = yaml.safe_load(open(tmp_path / "TOYdmodel4-seed1919-num_layers{0}-dqk16-conv_dim0-lr0.01-perf0.900".format(NL)
+                               / "used_config.yaml"))
+    assert "ssm_init: numpy" in used["analysis_notes"][0]
+
+
 def test_eval_eig_s4_all_columns_extension(pkg, tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     ev = sys.modules[pkg.__name__ + ".analysis.eval_eig"]

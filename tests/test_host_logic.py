@@ -105,6 +105,33 @@ def _gather_worker(rank, world, port, n_total, out_dir):
     dist.destroy_process_group()
 
 
+def _bootstrap_worker(rank, world, port, out_dir):
+    """What eval_eig does when it finds itself under a distributed launcher: join the group from the environment."""
+    import importlib
+    import torch
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank),
+                       "WORLD_SIZE": str(world), "EGS_DIST_BACKEND": "gloo"})
+    egs_dist = importlib.import_module("task-level-insights-from-eigenvalues-across-sequence-models_amd.dist")
+    r, w = egs_dist.bootstrap()
+    r2, w2 = egs_dist.bootstrap()                                          # idempotent
+    n_total, nb = 5, 7
+    lo, hi = egs_dist.shard_range(n_total)
+    want = torch.arange(nb * n_total * 2, dtype=torch.float64).reshape(nb, n_total, 2) / 3.0
+    mine = torch.zeros_like(want)
+    mine[:, lo:hi] = want[:, lo:hi]
+    got = egs_dist.all_reduce_slab_sum(mine)                               # histogram-only exchange: bit-exact
+    ok = (r, w, r2, w2) == (rank, world, rank, world) and torch.equal(got, want)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    torch.distributed.destroy_process_group()
+
+
+def test_bootstrap_from_env_and_histogram_exchange_world2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_bootstrap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]
+
+
 @pytest.mark.parametrize("n_total", [8, 7, 1])
 def test_all_gather_slabs_world2_gloo(tmp_path, n_total):
     """The N > 1 path: per-rank slabs (ragged when n is odd, empty when n < world) -> one all_gather."""
@@ -280,6 +307,20 @@ def test_orbax_chunked_arrays_and_placeholders(pkg, tmp_path):
     tree = {"w": {"__msgpack_chunked_array__": True, "shape": [2, 5], "chunks": {"0": big[:4], "1": big[4:]}}}
     pkg.ckpt.write_aggregate(str(tmp_path / "c1"), tree)
     np.testing.assert_array_equal(pkg.ckpt.read_aggregate(str(tmp_path / "c1"))["w"], big.reshape(2, 5))
+    # the layout flax.serialization really writes: the shape tuple as a {"0": n0, "1": n1} dict (_tuple_to_dict)
+    tree = {"w": {"__msgpack_chunked_array__": True, "shape": {"0": 5, "1": 2}, "chunks": {"0": big[:7], "1": big[7:]}}}
+    pkg.ckpt.write_aggregate(str(tmp_path / "c1b"), tree)
+    np.testing.assert_array_equal(pkg.ckpt.read_aggregate(str(tmp_path / "c1b"))["w"], big.reshape(5, 2))
+    import msgpack
+    os.makedirs(tmp_path / "c1c")
+    blob = msgpack.ExtType(1, msgpack.packb(([2], "bfloat16", b"\x80\x3f\x00\x40"), use_bin_type=True))
+    open(tmp_path / "c1c" / "checkpoint", "wb").write(msgpack.packb({"b": blob}, use_bin_type=True))
+    try:
+        import ml_dtypes  # noqa: F401
+        np.testing.assert_array_equal(pkg.ckpt.read_aggregate(str(tmp_path / "c1c"))["b"].astype(np.float32), [1.0, 2.0])
+    except ImportError:
+        with pytest.raises(NotImplementedError, match="bfloat16"):
+            pkg.ckpt.read_aggregate(str(tmp_path / "c1c"))
     pkg.ckpt.write_aggregate(str(tmp_path / "c2"), {"model": {"params": {"k": "PLACEHOLDER://model.params.k"}}})
     with pytest.raises(NotImplementedError):
         pkg.ckpt.read_aggregate(str(tmp_path / "c2"))
