@@ -121,13 +121,13 @@ __global__ __launch_bounds__(256) void hist_count_kernel(const void* __restrict_
                 }
             };
             int64_t t = t_begin + r0;
-            for (; t + 7 * rstep < t_end; t += 8 * rstep) {        // eight independent loads in flight per thread
+            for (; t + 3 * rstep < t_end; t += 4 * rstep) {        // four independent loads in flight per thread (eight: slower)
                 const int64_t base = (o * t_len + t) * inner + c;
-                double v[8];
+                double v[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = load_transformed<DTYPE>(vals, base + (int64_t)u * rstep * inner, transform);
+                for (int u = 0; u < 4; ++u) v[u] = load_transformed<DTYPE>(vals, base + (int64_t)u * rstep * inner, transform);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) tally(v[u]);
+                for (int u = 0; u < 4; ++u) tally(v[u]);
             }
             for (; t < t_end; t += rstep) tally(load_transformed<DTYPE>(vals, (o * t_len + t) * inner + c, transform));
             if constexpr (NE > 0) {
