@@ -701,6 +701,192 @@ static int softmax_nu_dispatch(const float* qk, int64_t nb, int64_t seqlen, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 2c. linear attention, FUSED: projection + phi + fp64 prefix + normaliser in one kernel -- q and k never exist in HBM.
+// get_eig_att_linear (analysis/eval_eig.py:97-135) needs nu_t = phi(q_t) . sum_{s<=t} phi(k_s) only; the unfused path
+// writes q,k (2 d_qk floats per token) and reads them back, 5x the algorithmic bytes.  Here one workgroup walks ONE
+// sequence tile by tile (128 tokens x all 2 d_qk = 256 projected columns on v_mfma_f32_32x32x2_f32, same tiling as
+// qk_proj_mfma2_kernel), and after each tile's products:
+//   * the waves holding the q columns and the k columns of 32 tokens put phi(q), phi(k) into LDS (the operand stages
+//     are free by then),
+//   * the four waves scan 8 tokens each in fp64: per-wave k sums first (one barrier), then S_t[d] = carry + earlier
+//     waves + own tokens, the products phi(q_t)[d] S_t[d] and one transpose-reduce per 8 tokens (lane = head dimension);
+//   * the fp64 carry S (one value per head dimension, held redundantly by every wave) moves on to the next round.
+// The next tile's first x / W stage is fetched during the epilogue.  Shapes: 2 d_qk == 256, H in {1, 2}, B >= the
+// number of resident workgroups that fills the chip; everything else keeps the two-kernel path.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kFusLd = 129;           // phi(q) / phi(k) slabs [32][129] floats: rows and columns conflict-free
+constexpr int kFusT = 512;            // 8 wavefronts: 2 x 4 waves of 64 x 64 (64 accumulator registers per lane)
+
+template <int HEADS>
+__global__ __launch_bounds__(kFusT, 1) void linattn_fused_kernel(const float* __restrict__ x, int64_t nseq, int64_t seqlen,
+                                                                 int d_model, const float* __restrict__ wt,
+                                                                 const float* __restrict__ bias, double* __restrict__ nu) {
+    constexpr int n_cols = kM2C;                       // 2 d_qk == 256
+    __shared__ float as[kM2R][kM2LdA];
+    __shared__ __attribute__((aligned(16))) float bs[kM2K][kM2LdB];
+    __shared__ double ksum[8][128];
+    extern __shared__ __attribute__((aligned(16))) float fus_dyn[];   // phi(q), phi(k) of the whole 128-token tile
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;           // rows wm*64.., columns wn*64..  (wn 0,1: q   wn 2,3: k)
+    const int kh = lane >> 5, l31 = lane & 31;
+    float* qslab = fus_dyn;                            // [64][kFusLd]
+    float* kslab = qslab + 64 * kFusLd;                // [64][kFusLd]    (one workgroup per CU: 66 KB + the stages)
+
+    // stage loads: x stage 128 x 32 floats = 1024 float4 (2 per thread), W^T stage 32 x 256 floats = 2048 float4 (4 per thread)
+    float4 xa0, xa1, wb0, wb1, wb2, wb3;
+    const int xr = tid >> 3, xq = tid & 7;             // rows xr + 64 e, k-quad xq
+    const int wk = tid >> 6, wq = tid & 63;            // k rows wk + 8 e, column quad wq
+    float bv[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) bv[tn] = bias ? bias[wn * 64 + tn * 32 + l31] : 0.0f;
+
+    for (int64_t seq = blockIdx.x; seq < nseq; seq += gridDim.x) {
+        const float* xs = x + seq * seqlen * d_model;
+#define FUS_XLOAD(XA, E, T0, K0)                                                                          \
+    {                                                                                                     \
+        const int64_t tk_ = (T0) + xr + 64 * (E);                                                         \
+        const int gk_ = (K0) + xq * 4;                                                                    \
+        const bool ok_ = tk_ < seqlen && gk_ < d_model;                                                   \
+        XA = *reinterpret_cast<const float4*>(xs + (ok_ ? tk_ * d_model + gk_ : 0));                      \
+        if (!ok_) XA = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+    }
+#define FUS_WLOAD(WB, E, K0)                                                                              \
+    {                                                                                                     \
+        const int gk_ = (K0) + wk + 8 * (E);                                                              \
+        const bool ok_ = gk_ < d_model;                                                                   \
+        WB = *reinterpret_cast<const float4*>(wt + (ok_ ? gk_ * n_cols + wq * 4 : 0));                    \
+        if (!ok_) WB = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+    }
+#define FUS_STAGE_LOAD(T0, K0)                                                                                     \
+    FUS_XLOAD(xa0, 0, T0, K0) FUS_XLOAD(xa1, 1, T0, K0)                                                            \
+    FUS_WLOAD(wb0, 0, K0) FUS_WLOAD(wb1, 1, K0) FUS_WLOAD(wb2, 2, K0) FUS_WLOAD(wb3, 3, K0)
+#define FUS_XSTORE(XA, E)                               \
+    {                                                   \
+        float* p_ = &as[xr + 64 * (E)][xq * 4];         \
+        p_[0] = XA.x;                                   \
+        p_[1] = XA.y;                                   \
+        p_[2] = XA.z;                                   \
+        p_[3] = XA.w;                                   \
+    }
+#define FUS_WSTORE(WB, E) *reinterpret_cast<float4*>(&bs[wk + 8 * (E)][wq * 4]) = WB;
+#define FUS_STAGE_STORE()                                                                 \
+    FUS_XSTORE(xa0, 0) FUS_XSTORE(xa1, 1)                                                 \
+    FUS_WSTORE(wb0, 0) FUS_WSTORE(wb1, 1) FUS_WSTORE(wb2, 2) FUS_WSTORE(wb3, 3)
+
+        // fp64 carry: S[d] for d = lane and lane + 64 (every wave keeps the same copy)
+        double carry0 = 0.0, carry1 = 0.0;
+        FUS_STAGE_LOAD(0, 0)
+        for (int64_t t0 = 0; t0 < seqlen; t0 += kM2R) {
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+            for (int k0 = 0; k0 < d_model; k0 += kM2K) {
+                __syncthreads();
+                FUS_STAGE_STORE()
+                __syncthreads();
+                if (k0 + kM2K < d_model) {
+                    FUS_STAGE_LOAD(t0, k0 + kM2K)
+                } else if (t0 + kM2R < seqlen) {
+                    FUS_STAGE_LOAD(t0 + kM2R, 0)       // next tile's first stage flies during the epilogue
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < kM2K / 2; ++k2) {
+                    const int kk = 2 * k2 + kh;
+                    const float a0 = as[wm * 32 + l31][kk];            // tokens wm*32 ..      (first half of the tile)
+                    const float a1 = as[64 + wm * 32 + l31][kk];       // tokens 64 + wm*32 .. (second half)
+                    const float b0 = bs[kk][wn * 64 + l31];
+                    const float b1 = bs[kk][wn * 64 + 32 + l31];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+            // ---- epilogue: two rounds of 64 tokens; in each, all 8 waves put phi of their 32 x 64 tile into LDS, then
+            // every wave scans 8 tokens ----
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                if (tm) __syncthreads();                   // the first round's slabs have been read
+                {
+                    float* slab = (wn >= 2) ? kslab : qslab;
+                    const int cbase = (wn & 1) * 64;
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[tm][tn][r] + bv[tn];
+                            v = (v > 0.0f) ? v + 1.0f : __expf(v);              // elu(v) + 1
+                            slab[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * kFusLd + cbase + tn * 32 + l31] = v;
+                        }
+                }
+                __syncthreads();
+                // tokens past the end of the sequence contribute nothing
+                const int64_t tok0 = t0 + tm * 64 + wave * 8;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int rr = wave * 8 + u;
+                    const bool ok = tok0 + u < seqlen;
+                    s0 += ok ? (double)kslab[rr * kFusLd + lane] : 0.0;
+                    s1 += ok ? (double)kslab[rr * kFusLd + 64 + lane] : 0.0;
+                }
+                ksum[wave][lane] = s0;
+                ksum[wave][64 + lane] = s1;
+                __syncthreads();
+                double st0 = carry0, st1 = carry1, tot0 = 0.0, tot1 = 0.0;
+#pragma unroll
+                for (int w2 = 0; w2 < 8; ++w2) {
+                    const double a = ksum[w2][lane], b = ksum[w2][64 + lane];
+                    st0 += (w2 < wave) ? a : 0.0;
+                    st1 += (w2 < wave) ? b : 0.0;
+                    tot0 += a;
+                    tot1 += b;
+                }
+                carry0 += tot0;
+                carry1 += tot1;
+                double p0[8], p1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int rr = wave * 8 + u;
+                    const bool ok = tok0 + u < seqlen;
+                    const float k0v = kslab[rr * kFusLd + lane], k1v = kslab[rr * kFusLd + 64 + lane];
+                    const float q0v = qslab[rr * kFusLd + lane], q1v = qslab[rr * kFusLd + 64 + lane];
+                    st0 += ok ? (double)k0v : 0.0;
+                    st1 += ok ? (double)k1v : 0.0;
+                    p0[u] = (double)q0v * st0;                                    // dims 0..63   (head 0 when H = 2)
+                    p1[u] = (double)q1v * st1;                                    // dims 64..127 (head 1 when H = 2)
+                }
+                const int64_t t = tok0 + (lane >> 3);                             // value index after the reduce = lane / 8
+                if constexpr (HEADS == 1) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) p0[u] += p1[u];
+                    treduce_t<double, 8, 32>(p0, lane);
+                    if ((lane & 7) == 0 && t < seqlen) nu[seq * seqlen + t] = p0[0];
+                } else {
+                    treduce_t<double, 8, 32>(p0, lane);
+                    treduce_t<double, 8, 32>(p1, lane);
+                    if ((lane & 7) == 0 && t < seqlen) {
+                        nu[(seq * 2 + 0) * seqlen + t] = p0[0];
+                        nu[(seq * 2 + 1) * seqlen + t] = p1[0];
+                    }
+                }
+            }
+        }
+#undef FUS_XLOAD
+#undef FUS_WLOAD
+#undef FUS_STAGE_LOAD
+#undef FUS_XSTORE
+#undef FUS_WSTORE
+#undef FUS_STAGE_STORE
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 3. eta[b, t, h] from nu[b, h, t] (and m[b, h, t] for softmax)
 // ---------------------------------------------------------------------------------------------------
 __global__ void eta_finalize_kernel(const double* __restrict__ nu, const float* __restrict__ mrow, int64_t nseq,
@@ -793,9 +979,43 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
                            d_model, wt);
         EGS_LAUNCH_CHECK();
     }
+    // fused linear-attention path: all projected columns in one 256-wide tile, one workgroup per sequence
+    const bool fused_lin = mfma2_ok && !softmax && n_cols == kM2C && (num_heads == 1 || num_heads == 2) &&
+                           batch >= 128 && !getenv("EGS_LINATTN_UNFUSED");
     for (int64_t b0 = 0; b0 < batch; b0 += chunk) {
         const int64_t nb = (batch - b0 < chunk) ? (batch - b0) : chunk;
         const int64_t rows = nb * seqlen;
+        if (fused_lin) {
+            const float* xin = x + b0 * seqlen * d_model;
+            static int cus = 0;
+            if (cus == 0) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                    cus = prop.multiProcessorCount;
+                if (cus <= 0) cus = 256;
+            }
+            const unsigned fgrid = (unsigned)(nb < cus ? nb : cus);           // one resident workgroup per CU walks sequences
+            const size_t fdyn = (size_t)2 * 64 * kFusLd * sizeof(float);
+            if (num_heads == 1) {
+                EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_fused_kernel<1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fdyn));
+                hipLaunchKernelGGL(linattn_fused_kernel<1>, dim3(fgrid), dim3(kFusT), fdyn, stream, xin, nb, seqlen, d_model,
+                                   wt, b_qk, nu);
+            } else {
+                EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_fused_kernel<2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fdyn));
+                hipLaunchKernelGGL(linattn_fused_kernel<2>, dim3(fgrid), dim3(kFusT), fdyn, stream, xin, nb, seqlen, d_model,
+                                   wt, b_qk, nu);
+            }
+            EGS_LAUNCH_CHECK();
+            const int64_t total = nb * (seqlen - 1) * num_heads;
+            const int64_t fb = (total + 255) / 256;
+            hipLaunchKernelGGL(eta_finalize_kernel, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(256), 0, stream, nu,
+                               mrow, nb, seqlen, num_heads, 0, eta + b0 * (seqlen - 1) * num_heads);
+            EGS_LAUNCH_CHECK();
+            continue;
+        }
         const dim3 pgrid((unsigned)((rows + kBM - 1) / kBM), (unsigned)((n_cols + kBN - 1) / kBN));
         const float* xin = x + b0 * seqlen * d_model;
         const bool fused_csum = mfma2_ok && !softmax && (seqlen % 32 == 0);

@@ -317,6 +317,25 @@ def test_attention_random_vs_oracle(gpu_ops, seqlen, d, d_qk, h):
     np.testing.assert_allclose(sm, O.eta_softmax(x, w, b, d_qk, h, d)[..., 0], rtol=5e-5)
 
 
+@pytest.mark.parametrize("heads", [1, 2])
+@pytest.mark.parametrize("seqlen", [128, 200, 391])
+def test_linear_attention_fused_path(gpu_ops, monkeypatch, heads, seqlen):
+    """The fused projection + prefix kernel (batch >= 128, 2 d_qk = 256, H in {1, 2}; q and k never reach HBM) against
+    the streaming oracle and against the two-kernel path on the same inputs, with sequence lengths that end inside a
+    128-token tile and inside a 32-token round."""
+    rng = np.random.default_rng(41 + seqlen + heads)
+    b, d, d_qk = 130, 64, 128
+    x = rng.standard_normal((b, seqlen, d)).astype(np.float32)
+    w = (rng.standard_normal((2 * d_qk + d, d)) / np.sqrt(d)).astype(np.float32)
+    bias = (rng.standard_normal(2 * d_qk + d) * 0.1).astype(np.float32)
+    got = gpu_ops.linattn_eta(dev(x), dev(w[:2 * d_qk]), dev(bias[:2 * d_qk]), d_qk, heads).cpu().numpy()
+    want = O.eta_linear_streaming(x[:6], w, bias, d_qk, heads, d)[..., 0]
+    np.testing.assert_allclose(got[:6], want, rtol=1e-5)
+    monkeypatch.setenv("EGS_LINATTN_UNFUSED", "1")
+    ref = gpu_ops.linattn_eta(dev(x), dev(w[:2 * d_qk]), dev(bias[:2 * d_qk]), d_qk, heads).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-9)          # same fp32 projection bit for bit, fp64 sums in another order
+
+
 def test_linear_attention_long_sequence_streaming_property(gpu_ops):
     """At a length the quadratic reference form cannot reach, check against the O(L) float64 restatement."""
     rng = np.random.default_rng(4096)
