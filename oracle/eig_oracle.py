@@ -14,7 +14,7 @@ from __future__ import annotations
 import numpy as np
 
 __all__ = [
-    "linear_f32", "eta_softmax", "eta_softmax_from_qk", "eta_linear", "eta_linear_streaming", "eta_norm",
+    "linear_f32", "eta_softmax", "eta_softmax_exact", "eta_softmax_from_qk", "eta_linear", "eta_linear_streaming", "eta_norm",
     "lambda_mamba2", "lambda_mamba2_lti",
     "discrete_dplr", "s4_dplr_ab", "s4_column_inputs", "eigvals_ssm", "lambda_lru", "lambda_s5",
     "radius", "phase_deg", "threshold_analysis", "threshold_analysis_ssm",
@@ -102,6 +102,31 @@ def eta_softmax(x, w_qkv, b_qkv, d_qk, num_heads, d_model):
     max_diff = (-row_max[:, 1:, :] + row_max[:, :-1, :]).astype(np.float64)   # :86-88 (fp32 diff, then f64)
     eta = eta * np.exp(max_diff)                                   # :90
     return eta[..., None]                                          # :93
+
+
+def eta_softmax_exact(x, w_qkv, b_qkv, d_qk, num_heads):
+    """The quantity analysis/eval_eig.py:43-95 defines (quirks Q3-Q5 kept: unscaled scores, zeros of the causal mask
+    take part in the row maximum, masked entries add exp(0 - m)), evaluated in float64 FROM the float32 inputs:
+    projection, scores, maxima, exponentials and sums all in double.  Both the reference (fp32 projection and scores)
+    and the HIP kernels approximate this; the tests measure each one's distance to it."""
+    x = np.asarray(x, np.float64)
+    w = np.asarray(w_qkv, np.float64)[:2 * d_qk]
+    b = np.asarray(b_qkv, np.float64)[:2 * d_qk]
+    qk = x @ w.T + b
+    bsz, seqlen, _ = x.shape
+    hd = d_qk // num_heads
+    q = qk[..., :d_qk].reshape(bsz, seqlen, num_heads, hd)
+    k = qk[..., d_qk:].reshape(bsz, seqlen, num_heads, hd)
+    scores = np.einsum("bthd,bshd->btsh", q, k)
+    tril = np.tril(np.ones((seqlen, seqlen)))
+    scores = scores * tril[None, :, :, None]                        # masked entries are exact zeros (Q5)
+    m = scores.max(axis=2)                                          # (B, L, H)
+    # the row maximum is subtracted from the causal entries only (:65-72): every masked entry adds exp(0) = 1 (Q4)
+    nu = (np.exp(scores - m[:, :, None, :]) * tril[None, :, :, None]).sum(axis=2) \
+        + (seqlen - 1 - np.arange(seqlen))[None, :, None]
+    with np.errstate(over="ignore", invalid="ignore"):
+        eta = nu[:, :-1] / nu[:, 1:] * np.exp(m[:, :-1] - m[:, 1:])
+    return eta[..., None]
 
 
 def eta_linear(x, w_qkv, b_qkv, d_qk, num_heads, d_model):

@@ -143,9 +143,17 @@ def test_eval_eig_transformer_families(pkg, tmp_path, monkeypatch, attention_fn)
     torch.manual_seed(1919)
     init = ToyTransformer(args["model"]).cuda()
     xs = _block_outputs(init, init.layers, loader[0][0])
-    if attention_fn == "lin-attention":
-        w0 = O.eta_linear(xs[0], _np(init.layers[0].attention.Wqkv.weight), _np(init.layers[0].attention.Wqkv.bias), DQK, H, D)
-        np.testing.assert_allclose(eig_init[..., :1], w0, rtol=5e-5)
+    want_init = []
+    for x, layer in zip(xs, init.layers):                      # every layer of the init pass, every family
+        if attention_fn == "sm-attention":
+            want_init.append(O.eta_softmax(x, _np(layer.attention.Wqkv.weight), _np(layer.attention.Wqkv.bias), DQK, H, D))
+        elif attention_fn == "lin-attention":
+            want_init.append(O.eta_linear(x, _np(layer.attention.Wqkv.weight), _np(layer.attention.Wqkv.bias), DQK, H, D))
+        else:
+            want_init.append(O.eta_norm(x, _np(layer.attention.Wvqkn.weight), _np(layer.attention.Wvqkn.bias),
+                                        _np(layer.attention.inner_attn.offset), "softplus", DQK, H, D))
+    np.testing.assert_allclose(eig_init, np.concatenate(want_init, axis=-1), rtol=5e-5)
+    np.testing.assert_array_equal(pct_init, O.threshold_analysis(eig_init, O.THRESHOLDS_RADIUS, NL, H, B))
 
     # artefacts (eval_eig.py:807-851) and the text report (eval_eig.py:393-433)
     name = "TOYdmodel{0}-seed1919-num_layers{1}-dqk{2}-conv_dim0-lr0.01-perf0.500".format(D, NL, DQK)
@@ -183,6 +191,19 @@ def test_eval_eig_mamba(pkg, tmp_path, monkeypatch, pseudo_lti):
                                         m.ngroups, m.d_state, m.nheads))
     want = np.concatenate(want, axis=-1)
     np.testing.assert_allclose(eig, want, rtol=1e-5, atol=1e-7)
+    # the init pass: a model built under torch.manual_seed(seed) (eval_eig.py:484), every layer
+    torch.manual_seed(1919)
+    init = ToyMamba(args["model"]).cuda()
+    xs_i = _block_outputs(init, init.blocks, loader[0][0])
+    want_i = []
+    for x, blk in zip(xs_i, init.blocks):
+        m = blk.mamba
+        if pseudo_lti:
+            want_i.append(O.lambda_mamba2_lti(x, _np(m.A), _np(m.beta)))
+        else:
+            want_i.append(O.lambda_mamba2(x, _np(m.in_proj.weight), None, _np(m.dt_bias), _np(m.A_log), m.d_inner,
+                                          m.ngroups, m.d_state, m.nheads))
+    np.testing.assert_allclose(eig_init, np.concatenate(want_i, axis=-1), rtol=1e-5, atol=1e-7)
     rad = np.sqrt(np.power(eig.real, 2) + np.power(eig.imag, 2))
     np.testing.assert_array_equal(pct, O.threshold_analysis(rad, O.THRESHOLDS_RADIUS, NL, 4, B))
     ph = np.arctan2(eig.imag, eig.real) * 180 / np.pi

@@ -290,16 +290,25 @@ def test_linear_attention_matches_golden(gpu_ops, golden, case, rtol):
     np.testing.assert_allclose(eta, g[f"linear_{case}"], rtol=rtol)
 
 
-@pytest.mark.parametrize("case,rtol", [("a", 2e-5), ("b", 1e-4), ("c", 2e-3)])
-def test_softmax_attention_matches_golden(gpu_ops, golden, case, rtol):
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_softmax_attention_matches_golden(gpu_ops, golden, case):
+    """The reference forms q.k in fp32, so its own eta carries the score noise e^(1e-7 |score|) -- 1e-6 in case a,
+    2e-4 in case c (|score| ~ 500).  A fixed rtol would either hide real differences in case a or have to be loosened
+    to case c's noise.  Instead both results are measured against the float64-exact value of the same formula
+    (oracle.eta_softmax_exact): the HIP path may be at most twice as far from it as the reference itself is."""
     g = golden("attention")
     d_qk, h = int(g["d_qk"]), int(g["H"])
     eta = gpu_ops.softmax_eta(dev(g[f"x_{case}"]), dev(g[f"w_{case}"][:2 * d_qk]), dev(g[f"b_{case}"][:2 * d_qk]),
                               d_qk, h).cpu().numpy()[..., None]
-    want = g[f"softmax_{case}"]
-    finite = np.isfinite(want)
-    assert np.array_equal(finite, np.isfinite(eta))
-    np.testing.assert_allclose(eta[finite], want[finite], rtol=rtol)
+    ref = g[f"softmax_{case}"]
+    with np.errstate(all="ignore"):
+        exact = O.eta_softmax_exact(g[f"x_{case}"], g[f"w_{case}"], g[f"b_{case}"], d_qk, h)
+    assert np.array_equal(np.isfinite(ref), np.isfinite(eta)) and np.array_equal(ref == 0, eta == 0)
+    ok = np.isfinite(exact) & (exact != 0) & np.isfinite(ref) & (ref != 0)
+    err_ref = np.max(np.abs(ref[ok] - exact[ok]) / np.abs(exact[ok]))
+    err_hip = np.max(np.abs(eta[ok] - exact[ok]) / np.abs(exact[ok]))
+    assert err_ref < 3e-4                                     # the reference's own distance (1.2e-6 / 1.5e-5 / 1.9e-4)
+    assert err_hip <= 2.0 * err_ref + 2e-7, (err_hip, err_ref)
 
 
 @pytest.mark.parametrize("seqlen,d,d_qk,h", [(130, 24, 48, 2), (64, 16, 16, 1), (257, 40, 160, 1), (2, 8, 8, 4),
