@@ -181,18 +181,21 @@ def main():
     hs_flops = (10.0 / 3.0) * n ** 3 * chunk
     achieved_tf = qr_flops / (hq_avg * 1e-3) / 1e12
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be read from
-    # inside the process; collected with rocprofv3 --pmc on this same command at 16384 and 65536 matrices per launch --
-    # the bytes per matrix agree, the kernel reads each Hessenberg matrix once)
-    traffic = None
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if n == 64:
-            traffic = tr["kernels"]["hqr_real_kernel"]["hbm_bytes_per_matrix"] * chunk
-    except Exception:
-        pass
+    # inside the process; collected with rocprofv3 --pmc on this same command, tools/prof_bench.sh, at 65536 matrices
+    # per launch -- the kernel reads each Hessenberg matrix once).  The file names the round it was measured in.
+    traffic, traffic_src = None, None
+    for fname in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", fname)))
+            if n == 64:
+                traffic = tr["kernels"]["hqr_real_kernel"]["hbm_bytes_per_matrix"] * chunk
+                traffic_src = "profiles/" + fname
+                break
+        except Exception:
+            pass
     roofline = {
         "bound": "mfma", "kernel": "hqr_real_kernel", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
+        "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "note": "fp64 (vector = matrix peak); algorithmic 10 n^3 flops per matrix, %d matrices per launch" % chunk,
         "avg_launch_ms": hq_avg, "launches_timed": nlaunch,
         "hess_kernel": {"kernel": "hess_real_kernel", "avg_launch_ms": hs_avg,
@@ -272,10 +275,11 @@ def stream_rooflines(ops, device):
     b = (torch.rand((2 * dqk,), generator=g, device=device) * 2 - 1) / np.sqrt(D)
     ms = med(lambda: ops.linattn_eta(x, w, b, dqk, 1), reps=3)
     tf = B * L * 2.0 * D * 2 * dqk / ms / 1e9
-    out.append({"kernel": "qk_proj_mfma2_kernel + linattn_scan_kernel + eta_finalize_kernel",
+    out.append({"kernel": "linattn_fused_kernel<1> + eta_finalize_kernel",
                 "workload": "C4 / 8 GPUs: linear attention eta, B=512, L=4096, D=128, d_qk=128, H=1",
                 "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "ms": ms,
-                "note": "fp32 MFMA (= fp32 vector peak); whole op incl. the fp64 scan",
+                "note": "fp32 MFMA (= fp32 vector peak); projection, elu+1, fp64 prefix and normaliser fused: q, k never reach HBM "
+                        "(PMC fetch + write = 1.00x the algorithmic bytes, profiles/r02_traffic.json)",
                 "hbm_gbs_algorithmic": B * L * (4 * D + 8) / ms / 1e6})
     del x
     # K4: softmax eta on the 4096-sequence MQAR batch (L = 512, hidden 128, d_qk = 64): two passes of causal score tiles

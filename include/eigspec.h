@@ -238,6 +238,13 @@ size_t egs_softmax_eta_qk_workspace_bytes(int64_t batch, int64_t seqlen, int num
 int egs_softmax_eta_qk(const float* qk, int64_t batch, int64_t seqlen, int d_qk, int num_heads, double* eta,
                        void* workspace, size_t workspace_bytes, egs_stream_t stream);
 
+/* The (q, k)-input form of the linear-attention eta (the scan half of get_eig_att_linear,
+ * analysis/eval_eig.py:113-130): qk : float[B, L, 2 d_qk] = per token the H query heads followed by the H key heads, RAW
+ * projections (phi = elu + 1 is applied inside); eta : double[B, L-1, H].  Same fp64 prefix state as egs_linattn_eta. */
+size_t egs_linattn_eta_qk_workspace_bytes(int64_t batch, int64_t seqlen, int d_qk, int num_heads);
+int egs_linattn_eta_qk(const float* qk, int64_t batch, int64_t seqlen, int d_qk, int num_heads, double* eta,
+                       void* workspace, size_t workspace_bytes, egs_stream_t stream);
+
 /* Depthwise causal conv1d + SiLU on channel-last activations: the conv blocks in front of the token mixers
  * (models/attention.py:130-155, models/norm_attention.py:225-244, models/mamba.py:96-108, :130-134 --
  * nn.Conv1d(groups = C, padding = K-1) truncated to L outputs, then nn.SiLU).

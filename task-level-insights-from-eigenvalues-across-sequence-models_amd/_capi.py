@@ -48,6 +48,8 @@ SIGNATURES = {
     "egs_threshold_hist": (_i, [_vp, _i, _i, _i64, _i64, _i64, _c.POINTER(_c.c_double), _i, _vp, _vp]),
     "egs_softmax_eta_qk_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "egs_softmax_eta_qk": (_i, [_vp, _i64, _i64, _i, _i, _vp, _vp, _sz, _vp]),
+    "egs_linattn_eta_qk_workspace_bytes": (_sz, [_i64, _i64, _i, _i]),
+    "egs_linattn_eta_qk": (_i, [_vp, _i64, _i64, _i, _i, _vp, _vp, _sz, _vp]),
     "egs_causal_conv1d_silu": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp]),
     "egs_layer_norm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _c.c_float, _vp]),
     "egs_softmax_attention_fwd": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i,

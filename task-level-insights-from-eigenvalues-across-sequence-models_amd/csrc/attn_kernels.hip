@@ -279,7 +279,10 @@ __device__ __forceinline__ void treduce_t(T* v, int lane) {
 // chunks as its carry-in.
 constexpr int kScanChunk = 256;
 
-template <int J>
+// RAW: qk holds raw projections (the (q, k)-input entry point): phi = elu + 1 is applied on load
+__device__ __forceinline__ float phi_elu1(float v) { return (v > 0.0f) ? v + 1.0f : __expf(v); }
+
+template <int J, bool RAW = false>
 __global__ __launch_bounds__(256) void linattn_chunksum_kernel(const float* __restrict__ qk, int64_t nseq, int64_t seqlen,
                                                                int d_qk, int num_heads, int nchunks,
                                                                double* __restrict__ csum) {
@@ -305,7 +308,8 @@ __global__ __launch_bounds__(256) void linattn_chunksum_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int d = lane + 64 * j;
-                const float kk = base[tt * 2 * d_qk + (d < hd ? d : hd - 1)];      // always-valid address
+                float kk = base[tt * 2 * d_qk + (d < hd ? d : hd - 1)];            // always-valid address
+                if (RAW) kk = phi_elu1(kk);
                 kv[u][j] = (d < hd && t + u < t_end) ? kk : 0.0f;
             }
         }
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void linattn_chunksum_kernel(const float* __re
     }
 }
 
-template <int J>   // head_dim <= 64*J
+template <int J, bool RAW = false>   // head_dim <= 64*J
 __global__ __launch_bounds__(256) void linattn_scan_kernel(const float* __restrict__ qk, int64_t nseq, int64_t seqlen,
                                                            int d_qk, int num_heads, int nchunks,
                                                            const double* __restrict__ csum, double* __restrict__ nu) {
@@ -361,8 +365,8 @@ __global__ __launch_bounds__(256) void linattn_scan_kernel(const float* __restri
             for (int j = 0; j < J; ++j) {
                 const int d = lane + 64 * j;
                 const int dc = (d < hd) ? d : hd - 1;
-                qv[u][j] = row[dc];
-                kv[u][j] = row[d_qk + dc];
+                qv[u][j] = RAW ? phi_elu1(row[dc]) : row[dc];
+                kv[u][j] = RAW ? phi_elu1(row[d_qk + dc]) : row[d_qk + dc];
             }
         }
 #pragma unroll
@@ -1064,6 +1068,50 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
                            nb, seqlen, num_heads, softmax ? 1 : 0, eta + b0 * (seqlen - 1) * num_heads);
         EGS_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// linear-attention eta from q, k that already exist (raw projections, phi = elu + 1 applied on load): the scan half of
+// get_eig_att_linear (analysis/eval_eig.py:113-130) -- SURVEY.md 8(b) lists the (q, k) input form next to the x form
+size_t linattn_eta_qk_workspace_bytes(int64_t batch, int64_t seqlen, int d_qk, int num_heads) {
+    const int64_t nchunks = (seqlen + kScanChunk - 1) / kScanChunk;
+    return (size_t)batch * num_heads * seqlen * sizeof(double) + (size_t)batch * nchunks * d_qk * sizeof(double) + 512;
+}
+
+int linattn_eta_qk_launch(const float* qk, int64_t batch, int64_t seqlen, int d_qk, int num_heads, double* eta,
+                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (batch == 0 || seqlen <= 1) return 0;
+    const int hd = d_qk / num_heads;
+    if (hd > 512) {
+        set_error("linear-attention scan supports head_dim <= 512 (got %d)", hd);
+        return -4;
+    }
+    if (workspace_bytes < linattn_eta_qk_workspace_bytes(batch, seqlen, d_qk, num_heads)) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes,
+                  linattn_eta_qk_workspace_bytes(batch, seqlen, d_qk, num_heads));
+        return -7;
+    }
+    const int nchunks = (int)((seqlen + kScanChunk - 1) / kScanChunk);
+    double* nu = static_cast<double*>(workspace);
+    double* csum = nu + batch * num_heads * seqlen;
+    const int64_t tasks = batch * num_heads * nchunks;
+    const unsigned grid = (unsigned)((tasks + 3) / 4);
+#define EGS_SCAN_QK(JJ)                                                                                                   \
+    hipLaunchKernelGGL((linattn_chunksum_kernel<JJ, true>), dim3(grid), dim3(256), 0, stream, qk, batch, seqlen, d_qk,  \
+                       num_heads, nchunks, csum);                                                                        \
+    hipLaunchKernelGGL((linattn_scan_kernel<JJ, true>), dim3(grid), dim3(256), 0, stream, qk, batch, seqlen, d_qk,      \
+                       num_heads, nchunks, csum, nu);
+    if (hd <= 64) { EGS_SCAN_QK(1) }
+    else if (hd <= 128) { EGS_SCAN_QK(2) }
+    else if (hd <= 256) { EGS_SCAN_QK(4) }
+    else { EGS_SCAN_QK(8) }
+#undef EGS_SCAN_QK
+    EGS_LAUNCH_CHECK();
+    const int64_t total = batch * (seqlen - 1) * num_heads;
+    const int64_t fb = (total + 255) / 256;
+    hipLaunchKernelGGL(eta_finalize_kernel, dim3((unsigned)(fb < 8192 ? fb : 8192)), dim3(256), 0, stream, nu,
+                       (const float*)nullptr, batch, seqlen, num_heads, 0, eta);
+    EGS_LAUNCH_CHECK();
     return 0;
 }
 

@@ -43,6 +43,8 @@ int layer_norm_launch(const float*, int64_t, const float*, const float*, float*,
 int causal_conv1d_silu_launch(const float*, int64_t, int64_t, const float*, const float*, float*, int64_t, int64_t, int, int,
                               hipStream_t);
 size_t softmax_eta_qk_workspace_bytes(int64_t, int64_t, int);
+size_t linattn_eta_qk_workspace_bytes(int64_t, int64_t, int, int);
+int linattn_eta_qk_launch(const float*, int64_t, int64_t, int, int, double*, void*, size_t, hipStream_t);
 int softmax_eta_qk_launch(const float*, int64_t, int64_t, int, int, double*, void*, size_t, hipStream_t);
 int softmax_attn_fwd_launch(const float*, const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, float*,
                             int64_t, int64_t, int, int, int, float, hipStream_t);
@@ -394,6 +396,24 @@ int egs_softmax_eta_qk(const float* qk, int64_t batch, int64_t seqlen, int d_qk,
     EGS_ARG(eta != nullptr, 6);
     EGS_ARG(workspace != nullptr, 7);
     return softmax_eta_qk_launch(qk, batch, seqlen, d_qk, num_heads, eta, workspace, workspace_bytes, as_stream(stream));
+}
+
+size_t egs_linattn_eta_qk_workspace_bytes(int64_t batch, int64_t seqlen, int d_qk, int num_heads) {
+    if (batch <= 0 || seqlen <= 0 || d_qk <= 0 || num_heads <= 0) return 512;
+    return linattn_eta_qk_workspace_bytes(batch, seqlen, d_qk, num_heads);
+}
+
+int egs_linattn_eta_qk(const float* qk, int64_t batch, int64_t seqlen, int d_qk, int num_heads, double* eta,
+                       void* workspace, size_t workspace_bytes, egs_stream_t stream) {
+    EGS_ARG(batch >= 0, 2);
+    EGS_ARG(seqlen >= 0, 3);
+    EGS_ARG(d_qk > 0, 4);
+    EGS_ARG(num_heads > 0 && d_qk % num_heads == 0 && num_heads <= 65535, 5);
+    if (batch == 0 || seqlen <= 1) return 0;
+    EGS_ARG(qk != nullptr, 1);
+    EGS_ARG(eta != nullptr, 6);
+    EGS_ARG(workspace != nullptr, 7);
+    return linattn_eta_qk_launch(qk, batch, seqlen, d_qk, num_heads, eta, workspace, workspace_bytes, as_stream(stream));
 }
 
 int egs_causal_conv1d_silu(const float* x, int64_t x_batch_stride, int64_t x_token_stride, const float* w,

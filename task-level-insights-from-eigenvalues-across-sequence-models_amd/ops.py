@@ -400,6 +400,27 @@ def softmax_eta_from_qk(q, k):
     return eta
 
 
+def linattn_eta_from_qk(q, k):
+    """Linear-attention eta from existing raw projections q, k [B, L, H, hd] (phi = elu + 1 applied on the device):
+    float64 [B, L-1, H].  The (q, k)-input form of get_eig_att_linear (analysis/eval_eig.py:113-130)."""
+    _require_cuda(q, "q")
+    _require_cuda(k, "k")
+    if q.dim() != 4 or q.shape != k.shape:
+        raise ValueError(f"expected q, k [B, L, H, hd] of equal shape, got {tuple(q.shape)} and {tuple(k.shape)}")
+    batch, seqlen, heads, hd = q.shape
+    qk = torch.cat([q.reshape(batch, seqlen, heads * hd).float(), k.reshape(batch, seqlen, heads * hd).float()],
+                   dim=-1).contiguous()
+    eta = torch.empty((batch, max(seqlen - 1, 0), heads), dtype=torch.float64, device=q.device)
+    if batch == 0 or seqlen <= 1:
+        return eta
+    need = lib().egs_linattn_eta_qk_workspace_bytes(batch, seqlen, heads * hd, heads)
+    ws = _workspace(q.device, need)
+    with torch.cuda.device(q.device):
+        check(lib().egs_linattn_eta_qk(_ptr(qk), batch, seqlen, heads * hd, heads, _ptr(eta), _ptr(ws),
+                                       ws.numel() * ws.element_size(), _stream()), "egs_linattn_eta_qk")
+    return eta
+
+
 def causal_conv1d_silu(x, weight, bias=None):
     """silu(depthwise causal conv1d) on channel-last activations: x [B, L, C] (contiguous channels), weight [C, 1, K] or
     [C, K] (nn.Conv1d(groups=C).weight), bias [C] or None; K <= 8.  Returns [B, L, C] float32.

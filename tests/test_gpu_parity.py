@@ -345,6 +345,24 @@ def test_linear_attention_fused_path(gpu_ops, monkeypatch, heads, seqlen):
     np.testing.assert_allclose(got, ref, rtol=1e-9)          # same fp32 projection bit for bit, fp64 sums in another order
 
 
+@pytest.mark.parametrize("seqlen,d_qk,h", [(70, 16, 2), (300, 128, 1), (513, 192, 3)])
+def test_linear_attention_eta_from_existing_qk(gpu_ops, seqlen, d_qk, h):
+    """The (q, k)-input entry point (raw projections in, elu + 1 applied on the device) against the x-input path fed
+    the same projections, and against the oracle."""
+    rng = np.random.default_rng(seqlen + d_qk)
+    bsz, d = 3, 24
+    x = rng.standard_normal((bsz, seqlen, d)).astype(np.float32)
+    w = (rng.standard_normal((2 * d_qk + d, d)) / np.sqrt(d)).astype(np.float32)
+    b = (rng.standard_normal(2 * d_qk + d) * 0.1).astype(np.float32)
+    qk = O.linear_f32(x, w[:2 * d_qk], b[:2 * d_qk])
+    q = qk[..., :d_qk].reshape(bsz, seqlen, h, d_qk // h)
+    k = qk[..., d_qk:].reshape(bsz, seqlen, h, d_qk // h)
+    got = gpu_ops.linattn_eta_from_qk(dev(q), dev(k)).cpu().numpy()
+    np.testing.assert_allclose(got, O.eta_linear(x, w, b, d_qk, h, d)[..., 0], rtol=1e-5)
+    via_x = gpu_ops.linattn_eta(dev(x), dev(w[:2 * d_qk]), dev(b[:2 * d_qk]), d_qk, h).cpu().numpy()
+    np.testing.assert_allclose(got, via_x, rtol=2e-6)
+
+
 def test_linear_attention_long_sequence_streaming_property(gpu_ops):
     """At a length the quadratic reference form cannot reach, check against the O(L) float64 restatement."""
     rng = np.random.default_rng(4096)
