@@ -356,11 +356,19 @@ def stream_rooflines(ops, device):
 def cpu_baseline(a, budget_s, O):
     """The oracle's dense path (np.linalg.eigvals -> LAPACK dgeev, the same third-party arithmetic the reference
     calls at analysis/eval_eig.py:296) timed on this node's host cores on a bounded sample of the same matrices."""
+    # one BLAS thread = the reference's effective behaviour (stacked eigvals is a serial gufunc loop).  If the thread
+    # pool cannot be pinned, say so: `cores` then reports what the BLAS pool actually has, never a silent "1".
+    cores, pinned = 1, True
     try:
-        from threadpoolctl import threadpool_limits
+        from threadpoolctl import threadpool_limits, threadpool_info
         limiter = threadpool_limits(limits=1)
     except Exception:
-        limiter = None
+        limiter, pinned = None, False
+        try:
+            from threadpoolctl import threadpool_info
+            cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        except Exception:
+            cores = int(os.environ.get("OPENBLAS_NUM_THREADS", os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))
     done, spent = 0, 0.0
     blk = 1024
     while spent < budget_s and done + blk <= min(a.shape[0], 65536):
@@ -371,9 +379,9 @@ def cpu_baseline(a, budget_s, O):
         done += blk
     if limiter is not None:
         limiter.unregister() if hasattr(limiter, "unregister") else None
-    return {"value": done / spent, "unit": "spectra/s", "cores": 1, "kind": "port",
-            "sample": "first %d of the benchmark's own matrices, stacked np.linalg.eigvals, 1 thread, %.1f s"
-                      % (done, spent),
+    return {"value": done / spent, "unit": "spectra/s", "cores": cores, "kind": "port", "blas_threads_pinned": pinned,
+            "sample": "first %d of the benchmark's own matrices, stacked np.linalg.eigvals, %d thread(s), %.1f s"
+                      % (done, cores, spent),
             "host_cpu_count": os.cpu_count()}
 
 

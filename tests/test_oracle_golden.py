@@ -212,29 +212,6 @@ def test_notebook_softmax_eta_from_qk_golden(golden, case):
     np.testing.assert_allclose(got, want, rtol=3e-5)
 
 
-@pytest.mark.parametrize("cfg", [(12, 0, 11, 0), (12, 2, 9, 2), (12, 2, 9, 4), (8, 0, 7, 0), (6, 0, 1, 0), (7, 1, 3, 1),
-                                 (40, 0, 39, 0), (33, 5, 30, 17)])
-def test_register_carried_qr_sweep_prototype(cfg):
-    """oracle/zqr_carry_proto.py: the carried sweep planned for the n >= 128 complex solver reproduces the step-by-step
-    sweep (same reflectors, same matrix) while moving less than half of the elements through global memory."""
-    from oracle import zqr_carry_proto as P
-    n, l, i, m = cfg
-    rng = np.random.default_rng(sum(cfg))
-    a = np.triu(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)), -1)
-    if m > l:
-        a[m, m - 1] *= 1e-9                                              # a small (not negligible) subdiagonal above the start
-    t = 0.9 * a[i, i] + 0.1
-    plain, traffic_plain = P.sweep_plain(a, l, i, m, t)
-    carried, traffic_carried = P.sweep_carried(a, l, i, m, t)
-    np.testing.assert_allclose(carried, plain, rtol=0, atol=1e-12)
-    assert traffic_carried <= 0.52 * traffic_plain
-    # the sweep is a unitary similarity of the window: its eigenvalues are unchanged
-    w0 = np.sort_complex(np.linalg.eigvals(a[l:i + 1, l:i + 1]))
-    if m == l:
-        w1 = np.sort_complex(np.linalg.eigvals(carried[l:i + 1, l:i + 1]))
-        np.testing.assert_allclose(w1, w0, atol=1e-9)
-
-
 # ---- prototype of the level-3 complex solver (oracle/zms_proto.py) ------------------------------------------------------
 def test_zms_prototype_matches_lapack():
     """The NumPy restatement of csrc/eig_zlarge.hip (blocked Hessenberg + windowed multishift QR) against LAPACK:
