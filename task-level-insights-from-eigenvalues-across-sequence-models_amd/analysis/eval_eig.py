@@ -233,28 +233,33 @@ def get_init_layers_ssm(seed, data_config, train_config, model_config, SEQ_LEN, 
 
 
 def init_layers_ssm_numpy(kind, seed, model_config):
-    """NumPy-drawn stand-in for :func:`get_init_layers_ssm` for environments without jax/flax (analysis YAML key
-    ``ssm_init: numpy``).  The deterministic parts follow the reference exactly (HiPPO-LegS DPLR: models/common.py:
-    215-241, models/s4.py:192-215, models/s5.py:253-296); the random draws (log_step, nu/theta) follow the
-    reference's distributions (models/common.py:244-265, models/lru.py:26-33) but not JAX's PRNG stream, so init
-    spectra agree in distribution, not bitwise."""
-    rng = np.random.default_rng(seed)
+    """JAX-free stand-in for :func:`get_init_layers_ssm` (analysis YAML key ``ssm_init: numpy``).  The deterministic
+    parts follow the reference exactly (HiPPO-LegS DPLR: models/common.py:215-241, models/s4.py:192-215,
+    models/s5.py:253-296).  The random parts that reach the eigenvalues -- LRU nu / theta, S4 / S5 log_step, all
+    ``jax.random.uniform`` draws -- come from :mod:`jax_prng`, a NumPy restatement of jax's threefry PRNG and of the
+    keys flax hands to each parameter, evaluated in float32 like the reference.  That chain is pinned only by the
+    Threefry known-answer vectors (no jax / flax here to compare a whole ``model.init``): see jax_prng's header.
+    Parameters that do not reach the eigenvalues (B, C, D, gamma) are not produced."""
+    from . import jax_prng as jr
+    f32 = np.float32
     n, h, nl = model_config["state_dim"], model_config["hidden_dim"], model_config["num_layers"]
     dt_min, dt_max = model_config.get("dt_min", 0.001), model_config.get("dt_max", 0.1)
+    span, lo = np.log(dt_max) - np.log(dt_min), np.log(dt_min)            # models/common.py:259-261 (Python floats)
     layers = []
-    for _ in range(nl):
+    for li in range(nl):
         if kind == "lru":
             r_min, r_max = model_config.get("r_min", 0.0), model_config.get("r_max", 1.0)
             max_phase = model_config.get("max_phase", 6.28)
-            u1, u2 = rng.uniform(size=n), rng.uniform(size=n)
-            layers.append({"nu_log": np.log(-0.5 * np.log(u1 * (r_max ** 2 - r_min ** 2) + r_min ** 2)),
-                           "theta_log": np.log(max_phase * u2)})
+            u_theta, u_nu = jr.lru_uniforms(seed, li, n)
+            nu = np.log(f32(-0.5) * np.log(u_nu * f32(r_max ** 2 - r_min ** 2) + f32(r_min ** 2)))   # models/lru.py:26-28
+            theta = np.log(f32(max_phase) * u_theta)                                               # models/lru.py:31-33
+            layers.append({"nu_log": nu.astype(f32), "theta_log": theta.astype(f32)})
         elif kind == "s4":
             lam, p, b = _hippo_dplr(n)
+            u = jr.s4_log_step_uniforms(seed, li, h)
             layers.append({"Lambda_re": np.repeat(lam.real[:, None], h, 1), "Lambda_im": np.repeat(lam.imag[:, None], h, 1),
                            "P": np.repeat(p[:, None], h, 1), "B": np.repeat(b[:, None], h, 1),
-                           "C": rng.standard_normal((n, h, 2)) * 0.5 ** 0.5,
-                           "log_step": rng.uniform(np.log(dt_min), np.log(dt_max), (1, h))})
+                           "log_step": (u * f32(span) + f32(lo)).astype(f32)[None, :]})
         elif kind == "s5":
             blocks = model_config.get("num_blocks", 8)
             bs = n // blocks
@@ -263,8 +268,10 @@ def init_layers_ssm_numpy(kind, seed, model_config):
             if model_config.get("conj_sym", True):
                 bs, pp = bs // 2, n // 2
             lam = np.tile(lam[:bs], blocks)
+            u = jr.s5_log_step_uniforms(seed, li, pp, model_config.get("bidirectional", False),
+                                        model_config.get("C_init", "lecun_normal"))
             layers.append({"Lambda_re": lam.real, "Lambda_im": lam.imag,
-                           "log_step": rng.uniform(np.log(dt_min), np.log(dt_max), (pp, 1))})
+                           "log_step": (u * f32(span) + f32(lo)).astype(f32)[:, None]})
         else:
             raise RuntimeError("{0} is not a valid model option".format(kind))
     return layers
@@ -515,9 +522,11 @@ def eval_eig(args, conf_args, wandb_config, data_config, loader, path_file, perf
             raise ValueError("analysis config key 'ssm_init' must be 'jax' or 'numpy', got {0!r}".format(ssm_init))
         if ssm_init == "numpy":
             note = ("ssm_init: numpy -- the random parts of the {0} initialisation (log_step / nu / theta) were drawn "
-                    "with NumPy's generator from the reference's distributions, NOT from JAX's PRNG stream: eig_init, "
-                    "percentage_init and percentage_phase_init agree with the reference in distribution, not "
-                    "bitwise".format(layer_type))
+                    "by a NumPy restatement of jax's threefry PRNG and flax's parameter keys (analysis/jax_prng.py), "
+                    "not by jax itself; that chain is pinned by the Threefry known-answer vectors only, so eig_init, "
+                    "percentage_init and percentage_phase_init are guaranteed to follow the reference's "
+                    "distributions and are bit-identical to it only if the restated key derivation is "
+                    "exact".format(layer_type))
             warnings.warn(note, stacklevel=2)
             args["analysis_notes"] = [note]                              # lands in used_config.yaml next to the arrays
             init_layers = init_layers_ssm_numpy(layer_type, seed, model_config)

@@ -188,6 +188,35 @@ def test_numpy_ssm_init_follows_reference_structure(pkg):
         ev.init_layers_ssm_numpy("s6", 0, cfg)
 
 
+def test_jax_free_prng_known_answers(pkg):
+    """analysis/jax_prng.py against published values: the three Threefry-2x32 known-answer vectors of the Random123
+    distribution (also jax's own tests), and the two values jax's documentation shows for PRNGKey(0) --
+    random.split(key) and random.uniform(key).  These pin the block function, split and the bits -> float32 step; the
+    flax key-derivation chain on top of them has no fixture (no jax / flax here) and is labelled unpinned."""
+    jr = sys.modules[pkg.__name__ + ".analysis.eval_eig"].__dict__.get("jr") or __import__(
+        "importlib").import_module(pkg.__name__ + ".analysis.jax_prng")
+    kat = [((0, 0), (0, 0), (0x6B200159, 0x99BA4EFE)),
+           ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+           ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0))]
+    for key, ctr, want in kat:
+        y0, y1 = jr.threefry2x32(key, [ctr[0]], [ctr[1]])
+        assert (int(y0[0]), int(y1[0])) == want
+    np.testing.assert_array_equal(jr.prng_key(0), [0, 0])
+    np.testing.assert_array_equal(jr.split(jr.prng_key(0), 2), [[4146024105, 967050713], [2718843009, 1272950319]])
+    assert float(jr.uniform(jr.prng_key(0), ())) == np.float32(0.41845703)
+    u = jr.uniform(jr.prng_key(7), (1001,))                      # odd count: padded block, pad dropped
+    assert u.dtype == np.float32 and u.shape == (1001,) and u.min() >= 0.0 and u.max() < 1.0
+    assert abs(float(u.mean()) - 0.5) < 0.05
+    # structure of the derived keys: per-layer, per-parameter, per-column keys are all distinct and reproducible
+    a, b = jr.lru_uniforms(1919, 0, 16)
+    a2, _ = jr.lru_uniforms(1919, 0, 16)
+    c, _ = jr.lru_uniforms(1919, 1, 16)
+    assert np.array_equal(a, a2) and not np.array_equal(a, b) and not np.array_equal(a, c)
+    s4 = jr.s4_log_step_uniforms(3, 0, 8)
+    assert len(set(s4.tolist())) == 8
+    assert jr.s5_log_step_uniforms(3, 0, 5).shape == (5,)
+
+
 def test_eval_eig_rejects_unknown_layer_like_the_reference(pkg):
     args = {"model": {"layer": "rnn", "num_layers": 1}, "train": {}, "dataset": {}, "seed": 0}
     with pytest.raises(RuntimeError, match="rnn is not a valid model option"):
