@@ -85,11 +85,18 @@ def main():
             cpu_multi = {"error": repr(exc)}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the eigenvalue-analysis path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; EGS_DIST_BACKEND=gloo (host-staged collectives, several ranks may share a GPU) exists so that the
+    # N > 1 path can be rehearsed on a one-GPU box -- the driver's runs use the default, "nccl" (= RCCL over xGMI)
+    backend = os.environ.get("EGS_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     pkg = importlib.import_module(PKG)
     ops, egs_dist = pkg.ops, pkg.dist
     import oracle as O
@@ -121,10 +128,7 @@ def main():
         return w, info
 
     def _gather(w):
-        import torch.distributed as dist
-        out = torch.empty((world * nmat, n), dtype=torch.complex128, device=device)
-        dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(w))   # the ONE collective of the path
-        return out
+        return egs_dist.all_gather_slabs(w, world * nmat)            # the ONE collective of the path (RCCL all-gather)
 
     for _ in range(args.warmup):
         w, info = step()
@@ -141,7 +145,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
