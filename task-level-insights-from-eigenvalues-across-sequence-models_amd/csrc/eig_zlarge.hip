@@ -678,6 +678,15 @@ __device__ __forceinline__ void zchase3(zq* __restrict__ Wn, zq* __restrict__ Un
         __syncthreads();
         CSTAMP(1)
         // ---- phase 2: columns p, p+1 of the window (lane = row); next rotation by the look-ahead lanes ----
+        // the bulk loads are issued first so that, in the four waves that also carry look-ahead lanes, their LDS latency
+        // runs under the scalar chain
+        const int pwc = act ? pw : 0;
+        const zq c0 = Wn[lane * QLD + pwc], c1 = Wn[lane * QLD + pwc + 1];
+        zq ul = {0.0, 0.0}, u1 = {0.0, 0.0};
+        if (WITHU) {
+            ul = Un[lane * QLD + pwc];
+            u1 = Un[lane * QLD + pwc + 1];
+        }
         if (lwave) {
             __builtin_amdgcn_s_setprio(3);                             // the scalar chain is the critical path of the step
             const int tb1 = t + 1 - 2 * bg;
@@ -707,7 +716,6 @@ __device__ __forceinline__ void zchase3(zq* __restrict__ Wn, zq* __restrict__ Un
         }
         if (act) {
             const int rmaxw = ((p + 2 < i) ? p + 2 : i) - s;
-            const zq c0 = Wn[lane * QLD + pw], c1 = Wn[lane * QLD + pw + 1];
             zq y0, y1;
             zrot_cols(c, sn, c0, c1, y0, y1);
             if (lane <= rmaxw) {
@@ -716,9 +724,7 @@ __device__ __forceinline__ void zchase3(zq* __restrict__ Wn, zq* __restrict__ Un
             }
             if (WITHU) {
                 // column p of U is still in this wave's registers from the previous step (no other bulge touches it)
-                const zq ul = Un[lane * QLD + pw];
                 const zq u0 = qsel(ucv, ucar, ul);
-                const zq u1 = Un[lane * QLD + pw + 1];
                 zq v0, v1;
                 zrot_cols(c, sn, u0, u1, v0, v1);
                 ucv = t < t1 && p + 1 <= i - 1;                        // the bulge moves on inside this window
