@@ -86,10 +86,9 @@ int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const do
  *   info   : int32[nmat]; 0 = converged, k > 0 = QR failed to deflate with k eigenvalues outstanding
  *            (their slots hold NaN), as LAPACK's xHSEQR info.
  *   workspace : device scratch of egs_eig_workspace_bytes(dtype, nmat, n) bytes, 256-byte aligned.
- * n <= 64 real and n <= 64 complex run LDS-resident (one wavefront per matrix); 64 < n <= 96 one workgroup per
- * matrix out of an LDS copy; larger n (<= 1024; the reference's S4 state_dim 128 / 512 and config C5's 256) run the
- * level-3 path: blocked Householder reduction with fp64 matrix-core panel updates, then small-bulge multishift QR
- * (one workgroup of 16 wavefronts per matrix, working copy in the workspace).
+ * n <= 64 real and n <= 64 complex run LDS-resident (one wavefront per matrix); larger n (<= 1024; the reference's S4
+ * state_dim 128 / 512 and config C5's 256) run the level-3 path: blocked Householder reduction with fp64 matrix-core panel
+ * updates, then small-bulge multishift QR (one workgroup of 16 wavefronts per matrix, working copy in the workspace).
  * dtype EGS_F32 / EGS_C64 inputs are widened on load and solved in double precision (w stays complex128). */
 size_t egs_eig_workspace_bytes(int dtype, int64_t nmat, int n);
 int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int lda, int64_t stride,

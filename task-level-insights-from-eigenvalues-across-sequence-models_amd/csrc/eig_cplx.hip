@@ -472,8 +472,7 @@ int zhess64_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, in
                    int32_t* info, hipStream_t stream);
 
 size_t eig_cplx_workspace_bytes(int64_t nmat, int n) {
-    if (n > kCplxWaveMaxN && n <= kCplxLdsMaxN) return 256;
-    return (size_t)nmat * n * n * 2 * sizeof(double);
+    return (size_t)nmat * n * n * 2 * sizeof(double);          // working copy (n > 64: either path may be chosen)
 }
 
 int eig_zlarge_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, int64_t stride, double* w,
@@ -482,8 +481,16 @@ int eig_zlarge_launch(const void* a, bool in_real, int64_t nmat, int n, int lda,
 int eig_cplx_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, int64_t stride, double* w,
                     int32_t* info, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (nmat == 0 || n == 0) return 0;
-    // n > 96: level-3 path (eig_zlarge.hip); EGS_ZLARGE_OFF keeps the unblocked workgroup kernel below (A/B runs)
-    if (n > kCplxLdsMaxN && n <= 1024 && !getenv("EGS_ZLARGE_OFF"))
+    // n > 64: level-3 path (eig_zlarge.hip); EGS_ZLARGE_OFF / EGS_ZLARGE_MIN keep the unblocked workgroup kernel below for
+    // A/B runs
+    // every order above the wave-per-matrix kernels takes the level-3 path: measured 2.6-2.8x faster than the LDS-resident
+    // unblocked kernel below even at n = 72 ... 96 (768 matrices: 26.8 / 33.0 / 46.2 ms -> 10.3 / 12.3 / 16.5 ms)
+    int zl_min = kCplxWaveMaxN + 1;
+    if (const char* e = getenv("EGS_ZLARGE_MIN")) {       // tuning knob: smallest order that takes the level-3 path (> 64)
+        const int v = atoi(e);
+        if (v > kCplxWaveMaxN) zl_min = v;
+    }
+    if (n >= zl_min && n <= 1024 && !getenv("EGS_ZLARGE_OFF"))
         return eig_zlarge_launch(a, in_real, nmat, n, lda, stride, w, info, workspace, workspace_bytes, stream);
     if (n > 1024) {
         set_error("n = %d exceeds the supported maximum of 1024", n);

@@ -1,4 +1,4 @@
-// K5 (complex, n > 96): batched eigenvalues of dense complex128 matrices by LEVEL-3 algorithms, one workgroup of
+// K5 (complex, n > 64): batched eigenvalues of dense complex128 matrices by LEVEL-3 algorithms, one workgroup of
 // 16 wavefronts per matrix.
 //
 // Replaces np.linalg.eigvals(Ab) on the bilinear-discretised S4 DPLR matrix (analysis/eval_eig.py:296) at the orders
