@@ -35,7 +35,8 @@ def test_workspace_queries_are_host_only(pkg):
     assert lib.egs_eig_workspace_bytes(c.EGS_F64, 10, 64) == 10 * 64 * 64 * 8 + 256
     assert lib.egs_eig_workspace_bytes(c.EGS_C128, 768, 256) == 768 * 256 * 256 * 16     # workgroup path: full copy
     assert lib.egs_eig_workspace_bytes(c.EGS_C128, 768, 64) == 768 * 64 * 64 * 16       # Hessenberg hand-over
-    assert lib.egs_eig_workspace_bytes(c.EGS_C128, 10, 96) == 256                        # workgroup LDS path: none
+    assert lib.egs_eig_workspace_bytes(c.EGS_C128, 10, 96) == 10 * 96 * 96 * 16         # level-3 path: working copy
+    assert lib.egs_eig_workspace_bytes(c.EGS_C64, 10, 96) == 10 * 96 * 96 * 16 + 10 * 96 * 96 * 16   # + widened input
     assert lib.egs_eig_workspace_bytes(c.EGS_F64, 0, 64) == 256
     need = lib.egs_attn_workspace_bytes(64, 512, 128, 1)
     assert need >= 64 * 512 * 256 * 4 + 64 * 512 * 12
