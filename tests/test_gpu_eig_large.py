@@ -78,6 +78,30 @@ def test_dense_random_matches_lapack(gpu_ops, n, kind):
     np.testing.assert_allclose(w.sum(axis=1), np.trace(a, axis1=1, axis2=2), rtol=0, atol=1e-11 * n)
 
 
+def test_order_1000_single_matrix(gpu_ops):
+    """The NB = 4 / TPW = 4 instantiation (512 < n <= 1024), an order that is not a multiple of 16, one matrix."""
+    rng = np.random.default_rng(1000)
+    n = 1000
+    a = (rng.standard_normal((1, n, n)) + 1j * rng.standard_normal((1, n, n))) / np.sqrt(2 * n)
+    w, info = gpu_ops.eig_general_batched(dev(a))
+    assert int(info.abs().sum().item()) == 0
+    w = w.cpu().numpy()
+    assert O.max_abs_dlambda(w[0], np.linalg.eigvals(a[0])) < 1e-9
+    assert abs(w[0].sum() - np.trace(a[0])) < 1e-10 * n
+
+
+def test_round1_kernel_behind_the_ab_switch(gpu_ops, monkeypatch):
+    """EGS_ZLARGE_OFF keeps the unblocked workgroup kernel reachable for A/B timing: it must still be correct."""
+    rng = np.random.default_rng(8)
+    a = (rng.standard_normal((3, 90, 90)) + 1j * rng.standard_normal((3, 90, 90))) / np.sqrt(180.0)
+    new = gpu_ops.eig_general_batched(dev(a))[0].cpu().numpy()
+    monkeypatch.setenv("EGS_ZLARGE_OFF", "1")
+    old, info = gpu_ops.eig_general_batched(dev(a))
+    assert int(info.abs().sum().item()) == 0
+    ref = np.linalg.eigvals(a)
+    assert O.max_abs_dlambda(old.cpu().numpy(), ref) < 1e-9 and O.max_abs_dlambda(new, ref) < 1e-9
+
+
 @pytest.mark.parametrize("n", [128, 256, 512])
 def test_s4_random_dplr_columns_elementwise(gpu_ops, n):
     """Well-conditioned DPLR inputs through the fused build + solve: elementwise parity with LAPACK and the Cayley
