@@ -202,7 +202,7 @@ def main():
         "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
         "note": "fp64 (vector = matrix peak); algorithmic 10 n^3 flops per matrix, %d matrices per launch" % chunk,
         "avg_launch_ms": hq_avg, "launches_timed": nlaunch,
-        "hess_kernel": {"kernel": "hess_real_kernel", "avg_launch_ms": hs_avg,
+        "hess_kernel": {"kernel": "hess_reg_kernel", "avg_launch_ms": hs_avg,
                         "achieved_tflops": hs_flops / (hs_avg * 1e-3) / 1e12},
         "hbm_gbs_algorithmic": (n * n * 8 + 16 * n) * chunk / ((hq_avg + hs_avg) * 1e-3) / 1e9,
     }

@@ -241,8 +241,12 @@ def s4_column_inputs(layer, idx):
     lam_im = np.asarray(layer["Lambda_im"])[:, idx]
     Lambda = np.minimum(lam_re, -1e-4) + 1j * lam_im               # :288
     Bv = np.asarray(layer["B"])[:, idx]
-    Cm = np.asarray(layer["C"])[:, idx, :]
-    C_tilde = Cm[:, 0] + 1j * Cm[:, 1]
+    # C is sliced by the reference (:290-291) but its discretised form is discarded by the call at :294; parameter
+    # sets that only carry what reaches the eigenvalues (init_layers_ssm_numpy) have none
+    C_tilde = None
+    if "C" in layer:
+        Cm = np.asarray(layer["C"])[:, idx, :]
+        C_tilde = Cm[:, 0] + 1j * Cm[:, 1]
     Pv = np.asarray(layer["P"])[:, idx]
     return Lambda, Pv, Bv, C_tilde, step
 
@@ -288,6 +292,8 @@ def eigvals_ssm(model, layer_list, layer_nr, idx, seq_len, dtype=np.complex128):
     for an unknown family (:331-333)."""
     if model == "s4":
         Lambda, Pv, Bv, Ct, step = s4_column_inputs(layer_list[layer_nr], idx)
+        if Ct is None:
+            Ct = np.zeros_like(Bv)                                     # only feeds the discarded Cb
         Ab, _, _ = discrete_dplr(Lambda, Pv, Pv, Bv, Ct, step, seq_len, dtype=dtype)   # :294
         return eigvals_dense(Ab)[:, None]                          # :296-299
     if model == "s5":

@@ -815,6 +815,9 @@ static int set_lds_attrs() {
     return 0;
 }
 
+int hess_reg_launch(const double* a, int64_t nmat, int lda, int64_t stride, double* h, int32_t* scale_exp, int balance,
+                    hipStream_t stream);          // eig_real_reg.hip: n = 64 with the matrix in registers
+
 int hess_real_launch(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h, int32_t* scale_exp,
                      hipStream_t stream) {
     if (nmat == 0 || n == 0) return 0;
@@ -825,6 +828,8 @@ int hess_real_launch(const double* a, int64_t nmat, int n, int lda, int64_t stri
     // balancing (xGEBAL) belongs to the eigenvalue driver: the stand-alone Hessenberg entry point (scale_exp == null)
     // returns a matrix orthogonally similar to its input, without it
     const int balance = (scale_exp != nullptr && !getenv("EGS_NO_BALANCE")) ? 1 : 0;
+    if (n == 64 && !getenv("EGS_HESS_LDS"))       // A/B switch: the LDS-resident kernel below
+        return hess_reg_launch(a, nmat, lda, stride, h, scale_exp, balance, stream);
     hipLaunchKernelGGL(hess_real_kernel, dim3(gh), dim3(kHessWaves * kWave), hess_lds, stream, a, nmat, n, lda, stride,
                        h, scale_exp, balance);
     EGS_LAUNCH_CHECK();

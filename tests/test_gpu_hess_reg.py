@@ -1,0 +1,102 @@
+"""GPU tests of the register-resident Hessenberg kernel (csrc/eig_real_reg.hip: n = 64, the first stage behind
+np.linalg.eigvals at analysis/eval_eig.py:296 for BASELINE config C2), through the C ABI: the reduced matrix is upper
+Hessenberg and orthogonally similar to its input, it agrees with the LDS-resident kernel behind ``EGS_HESS_LDS=1``, and
+the whole solver matches LAPACK on the inputs that exercise xGEBAL's permutation and scaling inside the kernel."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_reduced_matrix_is_hessenberg_and_similar(gpu_ops):
+    rng = np.random.default_rng(640)
+    a = rng.standard_normal((48, 64, 64))
+    h = gpu_ops.hessenberg_batched(dev(a)).cpu().numpy()
+    assert np.all(np.tril(h, -2) == 0.0)
+    # orthogonal similarity: trace, Frobenius norm, trace of the square and the spectrum itself
+    np.testing.assert_allclose(np.trace(h, axis1=1, axis2=2), np.trace(a, axis1=1, axis2=2), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.linalg.norm(h, axis=(1, 2)), np.linalg.norm(a, axis=(1, 2)), rtol=1e-13)
+    np.testing.assert_allclose(np.einsum("bij,bji->b", h, h), np.einsum("bij,bji->b", a, a), rtol=0, atol=1e-10)
+    assert O.max_abs_dlambda(O.eigvals_dense(h), O.eigvals_dense(a)) < 1e-11
+
+
+def test_matches_the_lds_resident_kernel(gpu_ops, monkeypatch):
+    """Same algorithm (xGEHD2 with the same reflector convention), different summation order: the two reductions agree
+    element by element up to rounding."""
+    rng = np.random.default_rng(641)
+    a = rng.standard_normal((16, 64, 64))
+    h = gpu_ops.hessenberg_batched(dev(a)).cpu().numpy()
+    monkeypatch.setenv("EGS_HESS_LDS", "1")
+    h_lds = gpu_ops.hessenberg_batched(dev(a)).cpu().numpy()
+    np.testing.assert_allclose(h, h_lds, rtol=0, atol=5e-12)
+
+
+def test_strided_input(gpu_ops):
+    """lda > n: a 64 x 64 window of a wider array."""
+    rng = np.random.default_rng(642)
+    big = rng.standard_normal((5, 64, 96))
+    a = big[:, :, 16:80]
+    w, info = gpu_ops.eig_general_batched(dev(big)[:, :, 16:80])
+    assert int(info.abs().sum().item()) == 0
+    assert O.max_abs_dlambda(w.cpu().numpy(), np.linalg.eigvals(a)) < 1e-11
+
+
+def test_balancing_inside_the_kernel(gpu_ops):
+    """Rows / columns that isolate an eigenvalue (permutation through the global-memory copy), triangular and block
+    triangular matrices, graded scaling, zero / identity, entries near the ends of the exponent range."""
+    rng = np.random.default_rng(643)
+    cases = []
+    b = rng.standard_normal((64, 64)); b[5, :] = 0.0; b[5, 5] = 2.0; cases.append(b)
+    b = rng.standard_normal((64, 64)); b[:, 9] = 0.0; b[9, 9] = -1.0; b[40, :] = 0.0; b[40, 40] = 0.5; cases.append(b)
+    cases.append(np.triu(rng.standard_normal((64, 64))))
+    cases.append(np.tril(rng.standard_normal((64, 64))))
+    d = 2.0 ** rng.integers(-20, 20, 64)
+    cases.append(rng.standard_normal((64, 64)) * d[:, None] / d[None, :])
+    cases.append(np.zeros((64, 64)))
+    cases.append(np.eye(64))
+    cases.append(rng.standard_normal((64, 64)) * 1e-200)
+    cases.append(rng.standard_normal((64, 64)) * 1e200)
+    b = rng.standard_normal((64, 64)); b[32:, :32] = 0.0; cases.append(b)
+    p = rng.permutation(64)                                          # a permuted triangular matrix: everything isolates
+    cases.append(np.triu(rng.standard_normal((64, 64)))[np.ix_(p, p)])
+    c = np.stack(cases)
+    w, info = gpu_ops.eig_general_batched(dev(c))
+    assert int(info.abs().sum().item()) == 0
+    w = w.cpu().numpy()
+    ref = np.linalg.eigvals(c)
+    for m in range(len(cases)):
+        scale = max(1e-300, np.max(np.abs(ref[m])))
+        assert O.max_abs_dlambda(w[m] / scale, ref[m] / scale) < 1e-12, m
+    # triangular inputs: the eigenvalues are the diagonal, exactly (isolated one by one, never touched by arithmetic)
+    for m in (2, 3, 10):
+        assert np.array_equal(np.sort(w[m].real), np.sort(np.diag(c[m]))) and not np.any(w[m].imag), m
+
+
+def test_nonfinite_input_is_flagged(gpu_ops):
+    rng = np.random.default_rng(644)
+    bad = rng.standard_normal((3, 64, 64))
+    bad[1, 3, 4] = np.nan
+    bad[2, 0, 0] = np.inf
+    w, info = gpu_ops.eig_general_batched(dev(bad))
+    assert info.cpu().tolist() == [0, 64, 64]
+    w = w.cpu().numpy()
+    assert np.all(np.isnan(w[1:].real)) and O.max_abs_dlambda(w[0], np.linalg.eigvals(bad[0])) < 1e-11
+
+
+def test_large_batch_against_known_spectra(gpu_ops):
+    """A bench-like batch with prescribed spectra (ragged last workgroup: the count is not a multiple of 4)."""
+    from test_gpu_parity import known_spectrum_real
+    rng = np.random.default_rng(645)
+    a, lam = known_spectrum_real(rng, 4099, 64)
+    w, info = gpu_ops.eig_general_batched(dev(a))
+    assert int(info.abs().sum().item()) == 0
+    w = w.cpu().numpy()
+    np.testing.assert_allclose(np.sort(np.abs(w), axis=1), np.sort(np.abs(lam), axis=1), atol=1e-9)
+    np.testing.assert_allclose(w.sum(axis=1).real, np.trace(a, axis1=1, axis2=2), rtol=1e-10, atol=1e-10)
