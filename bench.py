@@ -152,12 +152,26 @@ def main():
     value = nmat * world / (elapsed / args.steps)
 
     # ---- per-kernel timing (HIP events on the launch stream) for the roofline object ----
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    hq_ms, hs_ms = [], []
-    chunk = min(nmat, 65536)             # the launch size the step uses (egs_eig_workspace_bytes: 64 Ki matrices)
-    hbuf = torch.empty((chunk, n, n), dtype=torch.float64, device=device)
-    lib = pkg._capi.lib()
+    # n = 64: the step is ONE launch of the fused kernel (eig_real64_kernel: Hessenberg reduction in registers + QR in
+    # LDS per wave, whole batch behind a work queue); ops launches on torch's current stream, which is the stream the
+    # events are recorded on.  Other orders: the two-kernel path, timed per stage below.
     import ctypes
+    lib = pkg._capi.lib()
+    fused = (n == 64) and not os.environ.get("EGS_EIG_UNFUSED")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    fused_ms = []
+    if fused:
+        for rep in range(4):
+            ev[0].record()
+            ops.eig_general_batched(a, workspace=workspace)
+            ev[1].record()
+            ev[1].synchronize()
+            if rep > 0:
+                fused_ms.append(ev[0].elapsed_time(ev[1]))
+    # the two stages as kernels of their own (egs_hessenberg_batched / egs_hseqr_batched), 64 Ki matrices per launch
+    hq_ms, hs_ms = [], []
+    chunk = min(nmat, 65536)
+    hbuf = torch.empty((chunk, n, n), dtype=torch.float64, device=device)
     wtmp = torch.empty((chunk, n), dtype=torch.complex128, device=device)
     itmp = torch.empty((chunk,), dtype=torch.int32, device=device)
     qbuf = torch.zeros((32,), dtype=torch.int64, device=device)       # work-queue counter of the QR kernel
@@ -183,28 +197,40 @@ def main():
     # algorithmic work per matrix: (10/3) n^3 Hessenberg + 10 n^3 QR flops; n^2*8 + 16 n bytes
     qr_flops = 10.0 * n ** 3 * chunk
     hs_flops = (10.0 / 3.0) * n ** 3 * chunk
-    achieved_tf = qr_flops / (hq_avg * 1e-3) / 1e12
+    stages = {"hess_kernel": {"kernel": "hess_reg_kernel" if n == 64 else "hess_real_kernel", "avg_launch_ms": hs_avg,
+                              "achieved_tflops": hs_flops / (hs_avg * 1e-3) / 1e12},
+              "hqr_real_kernel": {"avg_launch_ms": hq_avg, "achieved_tflops": qr_flops / (hq_avg * 1e-3) / 1e12,
+                                  "frac": qr_flops / (hq_avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+              "matrices_per_launch": chunk, "launches_timed": nlaunch}
+    if fused:
+        kname, per_launch, k_ms = "eig_real64_kernel", nmat, float(np.mean(fused_ms))
+        k_flops = (40.0 / 3.0) * n ** 3 * per_launch
+        note = ("fp64 (vector = matrix peak); algorithmic (40/3) n^3 flops per matrix (Hessenberg (10/3) n^3 + QR 10 n^3), "
+                "%d matrices per launch; `two_kernel_stages` times the same two stages as separate kernels" % per_launch)
+    else:
+        kname, per_launch, k_ms = "hqr_real_kernel", chunk, hq_avg
+        k_flops = qr_flops
+        note = "fp64 (vector = matrix peak); algorithmic 10 n^3 flops per matrix, %d matrices per launch" % chunk
+    achieved_tf = k_flops / (k_ms * 1e-3) / 1e12
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be read from
-    # inside the process; collected with rocprofv3 --pmc on this same command, tools/prof_bench.sh, at 65536 matrices
-    # per launch -- the kernel reads each Hessenberg matrix once).  The file names the round it was measured in.
+    # inside the process; collected with rocprofv3 --pmc on this same command, tools/prof_bench.sh).  The file names the
+    # round it was measured in.
     traffic, traffic_src = None, None
     for fname in ("r02_traffic.json", "r01_traffic.json"):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", fname)))
-            if n == 64:
-                traffic = tr["kernels"]["hqr_real_kernel"]["hbm_bytes_per_matrix"] * chunk
-                traffic_src = "profiles/" + fname
-                break
+            traffic = tr["kernels"][kname]["hbm_bytes_per_matrix"] * per_launch
+            traffic_src = "profiles/" + fname
+            break
         except Exception:
             pass
     roofline = {
-        "bound": "mfma", "kernel": "hqr_real_kernel", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
+        "bound": "mfma", "kernel": kname, "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-        "note": "fp64 (vector = matrix peak); algorithmic 10 n^3 flops per matrix, %d matrices per launch" % chunk,
-        "avg_launch_ms": hq_avg, "launches_timed": nlaunch,
-        "hess_kernel": {"kernel": "hess_reg_kernel", "avg_launch_ms": hs_avg,
-                        "achieved_tflops": hs_flops / (hs_avg * 1e-3) / 1e12},
-        "hbm_gbs_algorithmic": (n * n * 8 + 16 * n) * chunk / ((hq_avg + hs_avg) * 1e-3) / 1e9,
+        "note": note, "avg_launch_ms": k_ms, "launches_timed": len(fused_ms) if fused else nlaunch,
+        "two_kernel_stages": stages,
+        "hbm_gbs_algorithmic": (n * n * 8 + 16 * n) * per_launch / (k_ms * 1e-3) / 1e9 if fused
+        else (n * n * 8 + 16 * n) * chunk / ((hq_avg + hs_avg) * 1e-3) / 1e9,
     }
 
     # ---- HBM-bound kernels of the same path (north_star: >= 40 % of HBM peak on the scan kernels), timed live ----

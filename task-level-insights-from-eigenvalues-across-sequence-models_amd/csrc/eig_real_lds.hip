@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "egs_common.h"
+#include "hess_reg.h"
 
 namespace egs {
 
@@ -539,7 +540,7 @@ __device__ __forceinline__ void qr_step2(const V& H, int k, int l, int i, int la
 }
 
 template <class V>
-__device__ void hqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
+__device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
                          int32_t* __restrict__ info_out, const double rescale) {
     const double ulp = 2.220446049250313e-16;                      // dlamch('P')
     const double safmin = 2.2250738585072014e-308;
@@ -797,6 +798,77 @@ __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// n = 64, both stages in ONE kernel: each resident wave takes a matrix from the queue, reduces it to Hessenberg form
+// in registers (hess_reg.h: no LDS traffic for the matrix, VALU / MFMA work), drops the result into its half of the
+// pair array and runs the QR iteration there.  The Hessenberg matrix never touches HBM, the whole batch is one launch
+// (one tail instead of one per 64 Ki-matrix chunk), and because the waves of a SIMD are at different points of their
+// matrices the VALU-dense reduction of one wave fills issue slots that the latency-bound QR sweep of its neighbour
+// leaves empty.  Only the two n = 64 layouts are instantiated here.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kFusedWaves = 4;                                   // 2 pairs per workgroup, 2 workgroups per CU
+constexpr int kFusedPairDoubles = 64 * 71;                       // hqr_pair_ld(64) = 71
+constexpr size_t kFusedLds = (size_t)(2 * kFusedPairDoubles + kFusedWaves * kRegVec) * sizeof(double);
+
+template <class V>
+__device__ __forceinline__ void store_hessenberg(const V H, const double (&A)[16][4], const RegLane& L) {
+    // the Hessenberg part plus the two extra sub-diagonals a bulge may touch (zeros)
+#pragma unroll
+    for (int R = 0; R < 16; ++R)
+#pragma unroll
+        for (int C = 0; C < 4; ++C) {
+            const int row = 4 * R + L.q, col = 16 * C + L.c;
+            if (row <= col + 3) H.at(row, col) = (row <= col + 1) ? A[R][C] : 0.0;
+        }
+}
+
+__global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
+    const double* __restrict__ a, int64_t nmat, int lda, int64_t stride, double* __restrict__ w,
+    int32_t* __restrict__ info, double* __restrict__ scratch, int balance, unsigned long long* __restrict__ next_mat) {
+    extern __shared__ __attribute__((aligned(16))) double smem_fused[];
+    constexpr int n = 64, ldp = 71;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    double* base = smem_fused + (size_t)(wave >> 1) * kFusedPairDoubles;
+    double* vecs = smem_fused + 2 * kFusedPairDoubles + (size_t)wave * kRegVec;
+    RegLane L;
+    reg_lane_init(L, lane);
+    const int64_t first = (int64_t)blockIdx.x * kFusedWaves + wave;
+    const int64_t stride0 = (int64_t)gridDim.x * kFusedWaves;
+    double* my_scratch = scratch + first * (int64_t)(n * n);     // permutation path of the balancing only
+    for (int64_t mat = first; mat < nmat;) {
+        double* wo = w + mat * 2 * (int64_t)n;
+        double A[16][4];
+        const int e = hess_reg_reduce(A, L, a + mat * stride, lda, vecs, my_scratch, true, balance);
+        if (e == kNonFinite) {        // like numpy.linalg.eigvals, non-finite input is an error, not a spectrum
+            const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+            for (int j = lane; j < 2 * n; j += kWave) wo[j] = qnan;
+            if (lane == 0) info[mat] = n;
+        } else {
+            const double rescale = (e != 0) ? scalbn(1.0, e) : 1.0;
+            if ((wave & 1) == 0) {
+                const MatViewT<71, false> H{base + 7, ldp};
+                store_hessenberg(H, A, L);
+                wave_lds_sync();
+                hqr_wave(H, n, lane, wo, info + mat, rescale);
+            } else {
+                const MatViewT<71, true> H{base, ldp};
+                store_hessenberg(H, A, L);
+                wave_lds_sync();
+                hqr_wave(H, n, lane, wo, info + mat, rescale);
+            }
+        }
+        wave_lds_sync();                                          // this matrix's LDS traffic is complete before the next one
+        if (next_mat == nullptr) break;
+        unsigned long long nx = 0ULL;
+        if (lane == 0) nx = atomicAdd(next_mat, 1ULL);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(nx & 0xffffffffULL));
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(nx >> 32));
+        mat = stride0 + (int64_t)(((unsigned long long)hi << 32) | lo);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------
@@ -891,6 +963,34 @@ int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t s
         return -9;
     }
     double* hws = static_cast<double*>(workspace);
+    if (n == 64 && chunk >= kFusedWaves && !getenv("EGS_EIG_UNFUSED")) {     // A/B switch: the two-kernel path below
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eig_real64_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cus = prop.multiProcessorCount;
+            if (cus <= 0) cus = 256;
+        }
+        // one resident set of waves (two workgroups per CU) fed by a work queue; every wave owns one scratch slot of the
+        // workspace, so the grid never holds more waves than the workspace has slots
+        int64_t blocks = (nmat + kFusedWaves - 1) / kFusedWaves;
+        const int64_t resident = (int64_t)cus * (int64_t)((160 * 1024) / kFusedLds);
+        unsigned long long* queue = nullptr;
+        if (blocks > resident || blocks * kFusedWaves > chunk) {
+            if (blocks > resident) blocks = resident;
+            if (blocks * kFusedWaves > chunk) blocks = chunk / kFusedWaves;
+            queue = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + (size_t)chunk * per_mat);
+            EGS_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream));
+        }
+        const int balance = getenv("EGS_NO_BALANCE") ? 0 : 1;
+        hipLaunchKernelGGL(eig_real64_kernel, dim3((unsigned)blocks), dim3(kFusedWaves * kWave), kFusedLds, stream, a, nmat,
+                           lda, stride, w, info, hws, balance, queue);
+        EGS_LAUNCH_CHECK();
+        return 0;
+    }
     for (int64_t m0 = 0; m0 < nmat; m0 += chunk) {
         const int64_t cnt = (nmat - m0 < chunk) ? (nmat - m0) : chunk;
         int st = hess_real_launch(a + m0 * stride, cnt, n, lda, stride, hws, info + m0, stream);

@@ -39,13 +39,24 @@ def test_matches_the_lds_resident_kernel(gpu_ops, monkeypatch):
 
 
 def test_strided_input(gpu_ops):
-    """lda > n: a 64 x 64 window of a wider array."""
+    """lda > n through the C ABI itself: a 64 x 64 window of a wider row-major array (the Python wrapper would copy)."""
+    import importlib
+    capi = importlib.import_module(gpu_ops.__name__.rsplit(".", 1)[0] + "._capi")
     rng = np.random.default_rng(642)
     big = rng.standard_normal((5, 64, 96))
-    a = big[:, :, 16:80]
-    w, info = gpu_ops.eig_general_batched(dev(big)[:, :, 16:80])
+    t = dev(big)
+    nmat, n, lda = 5, 64, 96
+    w = torch.empty((nmat, n), dtype=torch.complex128, device="cuda")
+    info = torch.empty((nmat,), dtype=torch.int32, device="cuda")
+    need = capi.lib().egs_eig_workspace_bytes(capi.EGS_F64, nmat, n)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    st = capi.lib().egs_eig_general_batched(t.data_ptr() + 16 * 8, capi.EGS_F64, nmat, n, lda, n * lda, w.data_ptr(),
+                                            info.data_ptr(), ws.data_ptr(), need,
+                                            torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
     assert int(info.abs().sum().item()) == 0
-    assert O.max_abs_dlambda(w.cpu().numpy(), np.linalg.eigvals(a)) < 1e-11
+    assert O.max_abs_dlambda(w.cpu().numpy(), np.linalg.eigvals(big[:, :, 16:80])) < 1e-11
 
 
 def test_balancing_inside_the_kernel(gpu_ops):
@@ -100,3 +111,19 @@ def test_large_batch_against_known_spectra(gpu_ops):
     w = w.cpu().numpy()
     np.testing.assert_allclose(np.sort(np.abs(w), axis=1), np.sort(np.abs(lam), axis=1), atol=1e-9)
     np.testing.assert_allclose(w.sum(axis=1).real, np.trace(a, axis1=1, axis2=2), rtol=1e-10, atol=1e-10)
+
+
+def test_fused_kernel_equals_the_two_kernel_path(gpu_ops, monkeypatch):
+    """eig_real64_kernel (both stages in one kernel, work queue over the whole batch) performs the same arithmetic as
+    hess_reg_kernel + hqr_real_kernel: the spectra are bit-identical, also when the grid is smaller than the batch
+    (queue in use) and when a small caller-provided workspace limits the number of resident waves."""
+    rng = np.random.default_rng(646)
+    a = dev(rng.standard_normal((3001, 64, 64)))
+    w, info = gpu_ops.eig_general_batched(a)
+    assert int(info.abs().sum().item()) == 0
+    small = torch.empty(40 * 64 * 64 * 8 + 256, dtype=torch.uint8, device="cuda")      # 40 scratch slots -> 10 workgroups
+    w_small, info_small = gpu_ops.eig_general_batched(a, workspace=small)
+    monkeypatch.setenv("EGS_EIG_UNFUSED", "1")
+    w2, info2 = gpu_ops.eig_general_batched(a)
+    assert torch.equal(torch.view_as_real(w), torch.view_as_real(w2)) and torch.equal(info, info2)
+    assert torch.equal(torch.view_as_real(w_small), torch.view_as_real(w2)) and torch.equal(info_small, info2)
