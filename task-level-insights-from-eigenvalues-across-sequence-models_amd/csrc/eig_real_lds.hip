@@ -828,18 +828,26 @@ __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
     int32_t* __restrict__ info, double* __restrict__ scratch, int balance, unsigned long long* __restrict__ next_mat) {
     extern __shared__ __attribute__((aligned(16))) double smem_fused[];
     constexpr int n = 64, ldp = 71;
-    const int lane = threadIdx.x & (kWave - 1);
+    const int lane0 = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     double* base = smem_fused + (size_t)(wave >> 1) * kFusedPairDoubles;
     double* vecs = smem_fused + 2 * kFusedPairDoubles + (size_t)wave * kRegVec;
-    RegLane L;
-    reg_lane_init(L, lane);
     const int64_t first = (int64_t)blockIdx.x * kFusedWaves + wave;
     const int64_t stride0 = (int64_t)gridDim.x * kFusedWaves;
     double* my_scratch = scratch + first * (int64_t)(n * n);     // permutation path of the balancing only
     for (int64_t mat = first; mat < nmat;) {
+        // Everything both stages derive from the lane index (row / column indices, masks, LDS addresses) is invariant
+        // across matrices; hoisted out of this loop it would have to stay alive -- spilled -- across the register-hungry
+        // reduction.  An opaque per-matrix copy keeps those derivations (a few dozen integer instructions) inside the
+        // loop body.  (Only the integer: an opaque POINTER loses its LDS address space and turns every ds_ access into
+        // a flat one -- measured 1.7x slower.)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        RegLane L;
+        reg_lane_init(L, lane);
         double* wo = w + mat * 2 * (int64_t)n;
         double A[16][4];
+        // (wave priorities were tried both ways round -- reduction below / above the QR sweep: 2 - 3 % slower than none)
         const int e = hess_reg_reduce(A, L, a + mat * stride, lda, vecs, my_scratch, true, balance);
         if (e == kNonFinite) {        // like numpy.linalg.eigvals, non-finite input is an error, not a spectrum
             const double qnan = __longlong_as_double(0x7ff8000000000000LL);

@@ -258,6 +258,11 @@ __device__ __forceinline__ int hess_reg_reduce(double (&A)[16][4], const RegLane
     double* xs = vecs;
     double* ys = xs + 64;
     double* zs = ys + 64;
+    // Inside a per-matrix loop the 16 row offsets (4R + q) * lda and the element addresses of the scratch copy are loop
+    // invariants; hoisted, they occupy ~150 registers across the whole reduction and are spilled.  Opaque copies keep
+    // their computation here (16 multiply-adds per matrix) and in the rare path.
+    asm volatile("" : "+s"(lda));
+    asm volatile("" : "+v"(scratch));
     double amax = 0.0;
     bool finite = true;
 #pragma unroll
