@@ -135,15 +135,18 @@ __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __re
 
     // x stage: thread -> rows (tid>>3) + 32 e, k-quad (tid&7);  Wt stage: thread -> k rows (tid>>6) + 4 e, column quad (tid&63)
     float4 xa0, xa1, xa2, xa3, wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7;
+    unsigned okm = 0u;                 // validity of the twelve staged loads (bits 0-3: x, 4-11: W)
     const int xr = tid >> 3, xq = tid & 7;
     const int wk = tid >> 6, wq = tid & 63;
+    // Loads always read a valid address and are zeroed when they are STORED to LDS one barrier later: a select right
+    // after the load makes the wave wait for the data at once, i.e. turns the prefetch into a synchronous load.
 #define EGS_XLOAD(XA, E, K0)                                                                              \
     {                                                                                                     \
         const int64_t gr_ = row0 + xr + 32 * (E);                                                         \
         const int gk_ = (K0) + xq * 4;                                                                    \
         const bool ok_ = gr_ < m_rows && gk_ < d_model;                                                   \
         XA = *reinterpret_cast<const float4*>(x + (ok_ ? gr_ * d_model + gk_ : 0));                       \
-        if (!ok_) XA = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+        okm = ok_ ? (okm | (1u << (E))) : (okm & ~(1u << (E)));                                           \
     }
 #define EGS_WLOAD(WB, E, K0)                                                                              \
     {                                                                                                     \
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __re
         const int gc_ = col0 + wq * 4;                                                                    \
         const bool ok_ = gk_ < d_model && gc_ < n_cols;                                                   \
         WB = *reinterpret_cast<const float4*>(wt + (ok_ ? (int64_t)gk_ * n_cols + gc_ : 0));              \
-        if (!ok_) WB = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+        okm = ok_ ? (okm | (16u << (E))) : (okm & ~(16u << (E)));                                         \
     }
 #define EGS_STAGE_LOAD(K0)                                                                                         \
     EGS_XLOAD(xa0, 0, K0) EGS_XLOAD(xa1, 1, K0) EGS_XLOAD(xa2, 2, K0) EGS_XLOAD(xa3, 3, K0)                        \
@@ -159,13 +162,16 @@ __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __re
     EGS_WLOAD(wb4, 4, K0) EGS_WLOAD(wb5, 5, K0) EGS_WLOAD(wb6, 6, K0) EGS_WLOAD(wb7, 7, K0)
 #define EGS_XSTORE(XA, E)                               \
     {                                                   \
+        const bool ok_ = (okm >> (E)) & 1u;             \
         float* p_ = &as[xr + 32 * (E)][xq * 4];         \
-        p_[0] = XA.x;                                   \
-        p_[1] = XA.y;                                   \
-        p_[2] = XA.z;                                   \
-        p_[3] = XA.w;                                   \
+        p_[0] = ok_ ? XA.x : 0.0f;                      \
+        p_[1] = ok_ ? XA.y : 0.0f;                      \
+        p_[2] = ok_ ? XA.z : 0.0f;                      \
+        p_[3] = ok_ ? XA.w : 0.0f;                      \
     }
-#define EGS_WSTORE(WB, E) *reinterpret_cast<float4*>(&bs[wk + 4 * (E)][wq * 4]) = WB;
+#define EGS_WSTORE(WB, E)                                                                           \
+    *reinterpret_cast<float4*>(&bs[wk + 4 * (E)][wq * 4]) =                                        \
+        ((okm >> (4 + (E))) & 1u) ? WB : make_float4(0.f, 0.f, 0.f, 0.f);
 #define EGS_STAGE_STORE()                                                                 \
     EGS_XSTORE(xa0, 0) EGS_XSTORE(xa1, 1) EGS_XSTORE(xa2, 2) EGS_XSTORE(xa3, 3)           \
     EGS_WSTORE(wb0, 0) EGS_WSTORE(wb1, 1) EGS_WSTORE(wb2, 2) EGS_WSTORE(wb3, 3)           \
@@ -177,23 +183,32 @@ __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __re
         EGS_STAGE_STORE()
         __syncthreads();
         if (k0 + kM2K < d_model) { EGS_STAGE_LOAD(k0 + kM2K) }
+        // LDS operands of two k-pairs (16 MFMAs) fetched while the previous two's MFMAs run: left alone, the scheduler sinks
+        // each load to just before its consumer and every MFMA group waits an LDS round trip
+        float a0[2][2], a1[2][2], bq[2][2][4];
+        auto fetch = [&](int buf, int kb) {
 #pragma unroll
-        for (int k2 = 0; k2 < kM2K / 2; ++k2) {
-            const int kk = 2 * k2 + kh;
-            const float a0 = as[wm * 64 + l31][kk];
-            const float a1 = as[wm * 64 + 32 + l31][kk];
-            const float b0 = bs[kk][wn * 128 + l31];
-            const float b1 = bs[kk][wn * 128 + 32 + l31];
-            const float b2 = bs[kk][wn * 128 + 64 + l31];
-            const float b3 = bs[kk][wn * 128 + 96 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc[0][2], 0, 0, 0);
-            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b3, acc[0][3], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc[1][2], 0, 0, 0);
-            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b3, acc[1][3], 0, 0, 0);
+            for (int u = 0; u < 2; ++u) {
+                const int kk = 2 * (kb + u) + kh;
+                a0[buf][u] = as[wm * 64 + l31][kk];
+                a1[buf][u] = as[wm * 64 + 32 + l31][kk];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) bq[buf][u][c] = bs[kk][wn * 128 + 32 * c + l31];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int g = 0; g < kM2K / 4; ++g) {
+            if (g + 1 < kM2K / 4) fetch((g + 1) & 1, 2 * (g + 1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[g & 1][u], bq[g & 1][u][c], acc[0][c], 0, 0, 0);
+                    acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[g & 1][u], bq[g & 1][u][c], acc[1][c], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // Epilogue: bias + phi, then each 32x32 accumulator tile is transposed through a per-wave LDS patch so that the
