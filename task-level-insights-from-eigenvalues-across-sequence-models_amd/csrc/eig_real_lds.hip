@@ -35,6 +35,13 @@ struct MatViewT {
 // ---------------------------------------------------------------------------------------------------
 constexpr int kHessLd = 65;            // odd leading dimension: row and column sweeps conflict-free
 constexpr int kNonFinite = -2147483647;   // scale-slot sentinel: the input matrix holds NaN / Inf
+#ifndef EGS_LD64
+#define EGS_LD64 73
+#endif
+// pair-array leading dimension at n = 64 (>= n + 7, odd).  71 is the minimum; with 73 the DIAGONAL stride (ld + 1 = 74
+// doubles = 148 dwords, 20 mod 64) spreads the per-sweep diagonal reads of the deflation / start searches over 16 banks
+// instead of 4 (72 doubles = 144 dwords, 16 mod 64: 8-way conflicts), rows and columns stay conflict-free (146 dwords).
+constexpr int kLd64 = EGS_LD64;
 constexpr int kHessWaves = 4;          // matrices per workgroup (4 x 33,792 B = 135 KB LDS)
 constexpr int kHessStride = kWave * kHessLd + 2 * kWave;   // matrix + Householder vector v + update vector y, in doubles
 // the Householder entry v_i is wave-uniform: either a broadcast LDS read or two v_readlane of the lane-held copy
@@ -726,6 +733,7 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
 //   role 0: H(i,j) at row i, column j+7   (occupied: column >= row+4, since i <= j+3 during a chase)
 //   role 1: H(i,j) at row j, column i     (occupied: column <= row+3)
 __host__ __device__ inline int hqr_pair_ld(int n) {
+    if (n == 64) return kLd64;
     int ld = n + 7;
     return (ld & 1) ? ld : ld + 1;
 }
@@ -781,8 +789,8 @@ __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict_
         } else {
         const double rescale = scaled ? scalbn(1.0, info[mat]) : 1.0;
         if (n == 64) {
-            if ((wave & 1) == 0) hqr_run(MatViewT<71, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
-            else hqr_run(MatViewT<71, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
+            if ((wave & 1) == 0) hqr_run(MatViewT<kLd64, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
+            else hqr_run(MatViewT<kLd64, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
         } else {
             if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
             else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict_
 // leaves empty.  Only the two n = 64 layouts are instantiated here.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kFusedWaves = 4;                                   // 2 pairs per workgroup, 2 workgroups per CU
-constexpr int kFusedPairDoubles = 64 * 71;                       // hqr_pair_ld(64) = 71
+constexpr int kFusedPairDoubles = 64 * kLd64;                    // hqr_pair_ld(64)
 constexpr size_t kFusedLds = (size_t)(2 * kFusedPairDoubles + kFusedWaves * kRegVec) * sizeof(double);
 
 template <class V>
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
     const double* __restrict__ a, int64_t nmat, int lda, int64_t stride, double* __restrict__ w,
     int32_t* __restrict__ info, double* __restrict__ scratch, int balance, unsigned long long* __restrict__ next_mat) {
     extern __shared__ __attribute__((aligned(16))) double smem_fused[];
-    constexpr int n = 64, ldp = 71;
+    constexpr int n = 64, ldp = kLd64;
     const int lane0 = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     double* base = smem_fused + (size_t)(wave >> 1) * kFusedPairDoubles;
@@ -856,12 +864,12 @@ __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
         } else {
             const double rescale = (e != 0) ? scalbn(1.0, e) : 1.0;
             if ((wave & 1) == 0) {
-                const MatViewT<71, false> H{base + 7, ldp};
+                const MatViewT<kLd64, false> H{base + 7, ldp};
                 store_hessenberg(H, A, L);
                 wave_lds_sync();
                 hqr_wave(H, n, lane, wo, info + mat, rescale);
             } else {
-                const MatViewT<71, true> H{base, ldp};
+                const MatViewT<kLd64, true> H{base, ldp};
                 store_hessenberg(H, A, L);
                 wave_lds_sync();
                 hqr_wave(H, n, lane, wo, info + mat, rescale);
