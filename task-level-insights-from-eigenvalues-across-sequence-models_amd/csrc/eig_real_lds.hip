@@ -627,10 +627,11 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
                 if (s == 0.0) {
                     rt1r = rt1i = rt2r = rt2i = 0.0;
                 } else {
-                    h11 /= s;
-                    h21 /= s;
-                    h12 /= s;
-                    h22 /= s;
+                    const double rs = fast_rcp(s);                      // (shifts need no correctly rounded quotients)
+                    h11 *= rs;
+                    h21 *= rs;
+                    h12 *= rs;
+                    h22 *= rs;
                     const double tr = (h11 + h22) * 0.5;
                     const double det = (h11 - tr) * (h22 - tr) - h12 * h21;
                     const double rtdisc = sqrt(fabs(det));
@@ -664,14 +665,16 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
                 const double hm1m = H.at(mm + 1, mm);
                 const double hm1m1 = H.at(mm + 1, mm + 1);
                 double s = fabs(hmm - rt2r) + fabs(rt2i) + fabs(hm1m);
-                const double h21s = hm1m / s;
-                v0 = h21s * H.at(mm, mm + 1) + (hmm - rt1r) * ((hmm - rt2r) / s) - rt1i * (rt2i / s);
+                double rs = fast_rcp(s);                                // the start vector is only a direction
+                const double h21s = hm1m * rs;
+                v0 = h21s * H.at(mm, mm + 1) + (hmm - rt1r) * ((hmm - rt2r) * rs) - rt1i * (rt2i * rs);
                 v1 = h21s * (hmm + hm1m1 - rt1r - rt2r);
                 v2 = h21s * H.at(mm + 2, mm + 1);
                 s = fabs(v0) + fabs(v1) + fabs(v2);
-                v0 /= s;
-                v1 /= s;
-                v2 /= s;
+                rs = fast_rcp(s);
+                v0 *= rs;
+                v1 *= rs;
+                v2 *= rs;
                 if (mm == l) {
                     start_ok = true;
                 } else {
