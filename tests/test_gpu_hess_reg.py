@@ -127,3 +127,34 @@ def test_fused_kernel_equals_the_two_kernel_path(gpu_ops, monkeypatch):
     w2, info2 = gpu_ops.eig_general_batched(a)
     assert torch.equal(torch.view_as_real(w), torch.view_as_real(w2)) and torch.equal(info, info2)
     assert torch.equal(torch.view_as_real(w_small), torch.view_as_real(w2)) and torch.equal(info_small, info2)
+
+
+@pytest.mark.parametrize("nmat", [1, 2, 3, 5, 9])
+def test_tiny_batches(gpu_ops, nmat):
+    """Fewer matrices than a workgroup has waves, and ragged last workgroups (waves without a matrix leave at once)."""
+    rng = np.random.default_rng(650 + nmat)
+    a = rng.standard_normal((nmat, 64, 64))
+    w, info = gpu_ops.eig_general_batched(dev(a))
+    assert int(info.abs().sum().item()) == 0
+    assert O.max_abs_dlambda(w.cpu().numpy(), np.linalg.eigvals(a)) < 1e-11
+    h = gpu_ops.hessenberg_batched(dev(a)).cpu().numpy()
+    assert np.all(np.tril(h, -2) == 0.0) and O.max_abs_dlambda(O.eigvals_dense(h), O.eigvals_dense(a)) < 1e-11
+
+
+def test_two_streams_do_not_share_scratch(gpu_ops):
+    """Two batches solved concurrently on two torch streams (separate workspaces per stream in ops._workspace): each
+    kernel has its own queue counter and scratch slots."""
+    rng = np.random.default_rng(660)
+    a1 = dev(rng.standard_normal((4096, 64, 64)))
+    a2 = dev(rng.standard_normal((4096, 64, 64)))
+    w1_ref, _ = gpu_ops.eig_general_batched(a1)
+    w2_ref, _ = gpu_ops.eig_general_batched(a2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        w1, i1 = gpu_ops.eig_general_batched(a1)
+    with torch.cuda.stream(s2):
+        w2, i2 = gpu_ops.eig_general_batched(a2)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(w1), torch.view_as_real(w1_ref)) and int(i1.abs().sum().item()) == 0
+    assert torch.equal(torch.view_as_real(w2), torch.view_as_real(w2_ref)) and int(i2.abs().sum().item()) == 0
