@@ -30,6 +30,24 @@ PKG = "task-level-insights-from-eigenvalues-across-sequence-models_amd"
 
 FP64_PEAK_TFLOPS = 78.6        # MI355X fp64 vector = matrix peak (datasheet)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+CPU_POOL_PROCS = 16            # process pool of the multi-core CPU figure: the host-core share of ONE GPU on the bench box
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run (127.0.0.1 rendezvous) as
+    child processes and relay their output.  This parent never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
 
 
 def gen_known_spectrum(cnt, n, gen, device):
@@ -65,24 +83,39 @@ def main():
     ap.add_argument("--matrices", choices=["s5", "randn"], default="s5")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no hot path and no GPU: only the launcher + process-group plumbing of --gpus N (gloo), for the "
+                         "CPU test suite; prints a line with value = null")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Started bare (`python bench.py --gpus N`): become the launcher.  The N ranks are FRESH child processes started
+        # before this process has made any GPU call (it never makes one: it only relays rank 0's JSON line and the exit
+        # code), one rank per GPU over RCCL -- exactly the command the driver uses for N > 1.
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # best-effort all-core CPU figure: a separate process with a forked pool, started BEFORE this
-    # process initialises the GPU; 16 = the host-core share of one GPU on the bench box
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    # multi-core CPU figure: a separate process with a forked pool of CPU_POOL_PROCS workers (NOT all of
+    # the host's cores: `cores` and `host_cpu_count` are both in the object), started BEFORE this process initialises
+    # the GPU
     cpu_multi = None
     if world == 1 and not args.no_cpu and args.n == 64:
         import subprocess
         try:
-            procs = max(1, min(16, os.cpu_count() or 1))
+            procs = max(1, min(CPU_POOL_PROCS, os.cpu_count() or 1))
             out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--procs", str(procs),
                                   "--seconds", str(min(args.cpu_seconds, 10.0))], capture_output=True, text=True,
                                  timeout=120)
             cpu_multi = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as exc:            # the baseline is a courtesy figure; never fail the bench on it
             cpu_multi = {"error": repr(exc)}
+    if args.rehearse_launch:
+        return rehearse_launch(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the eigenvalue-analysis path has no CPU fallback")
     # one rank per GPU; EGS_DIST_BACKEND=gloo (host-staged collectives, several ranks may share a GPU) exists so that the
@@ -213,20 +246,14 @@ def main():
         note = "fp64 (vector = matrix peak); algorithmic 10 n^3 flops per matrix, %d matrices per launch" % chunk
     achieved_tf = k_flops / (k_ms * 1e-3) / 1e12
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be read from
-    # inside the process; collected with rocprofv3 --pmc on this same command, tools/prof_bench.sh).  The file names the
-    # round it was measured in.
-    traffic, traffic_src = None, None
-    for fname in ("r02_traffic.json", "r01_traffic.json"):
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", fname)))
-            traffic = tr["kernels"][kname]["hbm_bytes_per_matrix"] * per_launch
-            traffic_src = "profiles/" + fname
-            break
-        except Exception:
-            pass
+    # inside the process; collected with rocprofv3 --pmc on this same command, tools/prof_bench.sh + tools/make_traffic.py).
+    # Only the NEWEST traffic file counts, it must list the timed kernel, and it must have been measured on the kernel
+    # source this library was built from (sha256 of the kernel's source files, recorded by make_traffic.py): anything
+    # else is reported as traffic = null with the reason -- never a silent fall-back to an older round's number.
+    traffic, traffic_src, traffic_note = kernel_traffic(kname, per_launch)
     roofline = {
         "bound": "mfma", "kernel": kname, "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
         "note": note, "avg_launch_ms": k_ms, "launches_timed": len(fused_ms) if fused else nlaunch,
         "two_kernel_stages": stages,
         "hbm_gbs_algorithmic": (n * n * 8 + 16 * n) * per_launch / (k_ms * 1e-3) / 1e9 if fused
@@ -259,8 +286,11 @@ def main():
                        "d_state": n, "matrices_per_gpu": nmat, "matrix_kind": args.matrices,
                        "parallelism": "matrix-sharded x%d, one all_gather of spectra" % world},
             "max_abs_dlambda_vs_lapack": d_lapack, "max_abs_dlambda_vs_known": d_known, "unconverged": info_bad,
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_multi,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_pool": cpu_multi,
             "secondary_rooflines": secondary,
+            # what the process group actually looked like (so a SCALE record shows that RCCL saw N ranks on N devices)
+            "world": world, "dist_backend": backend if world > 1 else None,
+            "visible_devices": torch.cuda.device_count(), "device_name": torch.cuda.get_device_name(device),
         }
         if cpu is not None:
             result["speedup_vs_cpu_1core"] = value / cpu["value"]
@@ -269,6 +299,56 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def rehearse_launch(args, world, rank):
+    """The N-rank plumbing without the hot path: rendezvous, barrier, the path's ONE collective on a small host tensor."""
+    pkg = importlib.import_module(PKG)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    slab = torch.full((3, 4), float(rank), dtype=torch.complex128)
+    full = pkg.dist.all_gather_slabs(slab, 3 * world)
+    ok = bool(all(float(full[3 * r, 0].real) == r for r in range(world)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "eigen-spectra/sec", "value": None, "n_gpus": world, "world": world,
+                          "dist_backend": "gloo" if world > 1 else None, "rehearsal": True, "gather_ok": ok}))
+
+
+KERNEL_SOURCES = {      # the files a kernel is compiled from; their hash ties a PMC measurement to a build
+    "eig_real64_kernel": ("eig_real_lds.hip", "hess_reg.h", "egs_common.h"),
+    "hqr_real_kernel": ("eig_real_lds.hip", "egs_common.h"),
+}
+
+
+def kernel_source_sha(kname):
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES.get(kname, ()):
+        with open(os.path.join(ROOT, PKG, "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def kernel_traffic(kname, per_launch):
+    """(bytes per launch, source file, note) from the newest profiles/rNN_traffic.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True)
+    if not files:
+        return None, None, "no profiles/r*_traffic.json"
+    src = "profiles/" + os.path.basename(files[0])
+    try:
+        tr = json.load(open(files[0]))
+        ent = tr["kernels"][kname]
+    except Exception:
+        return None, src, "newest traffic file does not list %s" % kname
+    want, have = kernel_source_sha(kname), ent.get("source_sha")
+    if have != want:
+        return None, src, "stale: measured on kernel source %s, this build is %s" % (have, want)
+    return ent["hbm_bytes_per_matrix"] * per_launch, src, "PMC FETCH_SIZE x2 + WRITE_SIZE, kernel source %s" % want
 
 
 def stream_rooflines(ops, device):

@@ -1033,14 +1033,7 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
         const int64_t rows = nb * seqlen;
         if (fused_lin) {
             const float* xin = x + b0 * seqlen * d_model;
-            static int cus = 0;
-            if (cus == 0) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                    cus = prop.multiProcessorCount;
-                if (cus <= 0) cus = 256;
-            }
+            const int cus = current_device_cus();
             const unsigned fgrid = (unsigned)(nb < cus ? nb : cus);           // one resident workgroup per CU walks sequences
             const size_t fdyn = (size_t)2 * 64 * kFusLd * sizeof(float);
             if (num_heads == 1) {

@@ -180,6 +180,9 @@ int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int l
     const bool real = dtype == EGS_F64 || dtype == EGS_F32;
     const int st = widen_if_single(&a, dtype, nmat, n, &lda, &stride, workspace, workspace_bytes, as_stream(stream));
     if (st) return st;
+    // the widened copy lives in the tail of the workspace: the solver may only use the core region in front of it (it
+    // sizes its chunk and places its work-queue counter from the byte count it is given)
+    if (dtype == EGS_F32 || dtype == EGS_C64) workspace_bytes = align256(eig_core_workspace_bytes(real, nmat, n));
     if (real && n <= 64)
         return eig_real_lds_launch(static_cast<const double*>(a), nmat, n, lda, stride, w, info, workspace,
                                    workspace_bytes, as_stream(stream));

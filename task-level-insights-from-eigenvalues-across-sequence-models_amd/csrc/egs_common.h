@@ -32,6 +32,16 @@ int check_hip(hipError_t e, const char* what);
 
 inline hipStream_t as_stream(egs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Compute units of the CURRENT device (queried per call: a process may drive several GPUs / partition modes, and the
+// resident grids of the work-queue kernels are sized from it).  hipDeviceGetAttribute is a table lookup, no device sync.
+inline int current_device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    return cus;
+}
+
 // ---- device-side helpers ---------------------------------------------------------------------------
 // LDS traffic of one wavefront is executed in order, so cross-lane hand-offs through LDS inside a wave
 // only need the compiler not to reorder the accesses: a wavefront-scope fence.

@@ -947,14 +947,7 @@ int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* in
     const size_t hqr_lds = pairs * pair_bytes;
     unsigned gq = (unsigned)((nmat + hqr_waves - 1) / hqr_waves);
     if (queue != nullptr && !getenv("EGS_HQR_NONPERSISTENT")) {   // one resident wave set + work queue
-        static int cus = 0;
-        if (cus == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                cus = prop.multiProcessorCount;
-            if (cus <= 0) cus = 256;
-        }
+        const int cus = current_device_cus();
         const unsigned resident = (unsigned)cus * (unsigned)((160 * 1024) / hqr_lds);
         if (gq > resident) {
             gq = resident;
@@ -985,14 +978,7 @@ int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t s
     if (n == 64 && chunk >= kFusedWaves && !getenv("EGS_EIG_UNFUSED")) {     // A/B switch: the two-kernel path below
         EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eig_real64_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        static int cus = 0;
-        if (cus == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                cus = prop.multiProcessorCount;
-            if (cus <= 0) cus = 256;
-        }
+        const int cus = current_device_cus();
         // one resident set of waves (two workgroups per CU) fed by a work queue; every wave owns one scratch slot of the
         // workspace, so the grid never holds more waves than the workspace has slots
         int64_t blocks = (nmat + kFusedWaves - 1) / kFusedWaves;

@@ -38,3 +38,21 @@ def test_bench_line_schema_and_consistency():
     assert 0.5 * d["ms_per_step"] < r["avg_launch_ms"] <= 1.05 * d["ms_per_step"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2` started bare: two fresh ranks (both on this box's one GPU, collectives staged through gloo)
+    run the hot path on their own matrices and all-gather the spectra; the line reports the whole job."""
+    nmat = 8192
+    env = dict(os.environ, EGS_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--nmat", str(nmat), "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world"] == 2 and d["dist_backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["unconverged"] == 0 and d["max_abs_dlambda_vs_lapack"] < 1e-5
+    assert abs(d["value"] - 2 * nmat / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -239,6 +239,21 @@ def test_single_precision_entry(gpu_ops, dtype, n):
     assert O.max_abs_dlambda(w.cpu().numpy(), ref) < 1e-9
 
 
+@pytest.mark.parametrize("n", [64, 32])
+def test_single_precision_entry_many_matrices(gpu_ops, n):
+    """More float32 matrices than one solver chunk (65536): the widened fp64 copy sits in the tail of the workspace and
+    the solver must keep its Hessenberg chunk / work-queue counter inside the core region in front of it.  The spectra
+    must equal, bit for bit, those of the same matrices handed over as float64."""
+    nmat = 70000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(70000 + n)
+    a32 = torch.randn((nmat, n, n), generator=g, device="cuda", dtype=torch.float32) / np.sqrt(n)
+    w32, info32 = gpu_ops.eig_general_batched(a32)
+    w64, info64 = gpu_ops.eig_general_batched(a32.to(torch.float64))
+    assert int(info32.abs().sum().item()) == 0 and int(info64.abs().sum().item()) == 0
+    assert torch.equal(torch.view_as_real(w32), torch.view_as_real(w64))
+
+
 def test_c5_batch_properties(gpu_ops):
     """BASELINE config C5 at full size (768 matrices of order 256, HiPPO-DPLR columns with per-column steps):
     size-independent checks over the whole batch -- convergence flags, trace and trace of the square."""

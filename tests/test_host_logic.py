@@ -1,6 +1,7 @@
 """CPU-only tests of the host side: the C-ABI library loads and exports every symbol include/eigspec.h declares
 (no compute calls without a GPU), workspace queries, loud failure without a GPU, batch sharding + the all-gather
 (gloo, world_size 2), report writers, checkpoint readers, NumPy SSM init."""
+import json
 import os
 import re
 import socket
@@ -379,3 +380,28 @@ def test_dropin_models_have_reference_parameter_names_and_no_cpu_path(pkg, golde
             "blocks.0.mamba.conv1d.weight", "blocks.0.mamba.out_proj.weight"} <= set(mamba.state_dict())
     with pytest.raises(pkg._capi.EigspecError, match="no CPU fallback"):
         mamba.eval()(torch.zeros(1, 5, 3))
+
+
+def _bench_lines(argv, env=None, timeout=300):
+    import subprocess
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None), e.pop("RANK", None), e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                         timeout=timeout, env=e)
+    return out, [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` started bare must become a launcher for 2 fresh ranks (torch.distributed.run,
+    127.0.0.1 rendezvous) and relay exactly one JSON line saying so; the launcher/process-group plumbing is rehearsed
+    on the CPU with gloo (the hot path itself has no CPU form)."""
+    out, lines = _bench_lines(["--gpus", "2", "--rehearse-launch"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["world"] == 2 and lines[0]["gather_ok"] is True
+    assert lines[0]["dist_backend"] == "gloo"
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    out, lines = _bench_lines(["--gpus", "4", "--rehearse-launch"], env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert out.returncode != 0 and not lines and "--gpus 4" in (out.stderr + out.stdout)
