@@ -23,6 +23,7 @@ namespace egs {
 template <int LDP, bool TR>
 struct MatViewT {
     static constexpr bool kFast = LDP > 0;
+    static constexpr int kSR = TR ? 1 : LDP, kSC = TR ? LDP : 1;   // compile-time strides of the fast layouts (LDP > 0)
     double* hm;
     int ld;
     __device__ __forceinline__ int sr() const { return TR ? 1 : (LDP > 0 ? LDP : ld); }
@@ -546,6 +547,261 @@ __device__ __forceinline__ void qr_step2(const V& H, int k, int l, int i, int la
     wave_lds_sync();
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Two bulges per sweep, one HALF-WAVE each (the n = 64 layouts).
+//
+// A bulge step is ~22 vector instructions of wave-uniform reflector arithmetic plus two O(n) passes that use the lanes;
+// chasing ONE bulge per wavefront therefore spends most of its issue slots on work that 63 lanes repeat.  Here a sweep
+// chases TWO double-shift bulges, the second kBulgeDist = 4 rows behind the first, and the same instructions serve both:
+// lanes 0-31 (group 0) work for the leading bulge, lanes 32-63 (group 1) for the trailing one -- every "uniform" quantity
+// (bulge column, reflector, row / column indices) is uniform per half-wave, the row and column operations run as
+// sub-passes of 32 columns / rows per group.  At distance >= 4 the two row operations touch disjoint rows, the two
+// column operations disjoint columns, and no element receives a row operation of one bulge and a column operation of
+// the other in the same pass, so an iteration is (row passes of both) -> (column passes of both) and the result is that
+// of two consecutive sweeps with the same double shift (oracle/hqr2_proto.py restates the iteration and was checked
+// against LAPACK first: 0.66 iterations per single-bulge step on the benchmark's matrices).
+//
+// Other differences from qr_step3: (1) the bulge column is read back from LDS at the top of an iteration (three
+// broadcast reads per group) instead of six v_readlane; (2) it is not overwritten with (beta, 0, 0): column k-1 simply
+// takes part in the row operation, which leaves (beta~, eps, eps) -- rounding-level entries below the sub-diagonal
+// that later sweeps treat as data (a backward error of the size every other column already carries; exact zeros of a
+// reducible matrix stay exact because a zero tail gives u = 0); (3) lanes own FIXED columns (i - 31 + j | i - 63 + j)
+// and rows (l + j | l + 32 + j) for a whole sweep, so the address arithmetic of an iteration is three pointer
+// increments and validity is one compare of a per-lane constant with a wave-uniform counter per sub-pass.
+// Sweeps whose start row m lies below the top of the window (m > l, ~7 %) chase a single bulge (group 1 stays parked).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kBulgeDist = 4;
+constexpr int kNever = 1 << 20;               // validity constant of a lane that must not store
+
+// Reflector of the bulge column (a0; a1, a2) without beta.  nrm carries +1e-300 so that an all-zero column gives
+// t ~ 1e-150, u = 0 (the identity) and the reciprocal below needs no guard; a zero tail gives t1 = 2, u = 0.
+__device__ __forceinline__ void larfg3_coeffs(double a0, double a1, double a2, double& t1, double& t2, double& t3,
+                                              double& u1, double& u2) {
+    const double tiny = 1e-300;
+    const double nrm2 = fma(a0, a0, fma(a2, a2, a1 * a1));
+    const double rn = fast_rsqrt(fmax(nrm2, tiny));
+    const double apn = fabs(a0) + fma(nrm2, rn, tiny);             // |a0 - beta|
+    const double scal = copysign(fast_rcp(apn), a0);               // 1 / (a0 - beta)
+    t1 = apn * rn;                                                 // (beta - a0) / beta
+    u1 = a1 * scal;
+    u2 = a2 * scal;
+    t2 = t1 * u1;
+    t3 = t1 * u2;
+}
+
+struct Qr2Lane {
+    double* rowp;      // &H(k, c1): this lane's primary column of the row operation, at the group's bulge row k
+    double* colp;      // &H(r0, k): this lane's primary row of the column operation
+    double* bp;        // &H(k, k-1): the bulge column
+    int inc_r, inc_c, inc_b;   // advance per iteration in doubles (0 while the group is parked)
+    int d_r, d_c;      // element offset of the secondary column / row
+    int er;            // row pass:    primary valid <=> er <= L,  secondary <=> er <= L - 32
+    int ec0, ec1;      // column pass: primary valid <=> ec0 <= M, secondary <=> ec1 <= M
+};
+
+// One iteration: both groups advance their bulge by one row.
+//   GEN : an iteration in which some group takes its first step (bulge column = start vector; at the top of the window
+//         column l-1 is excluded) or its last one (order-2 reflector: third row / column untouched); `first`, `last`
+//         are per-lane (uniform per group).  At most four iterations of a sweep.
+//   R2 / C2 : some lane's secondary column lies inside [k-1, i] / secondary row inside [l, k+3].  Both are monotone in
+//         the iteration count, so a sweep is a handful of segments of constant (R2, C2) and the steady-state loop of
+//         a segment carries no uniform branch at all.
+// An iteration is two LDS round trips and the reflector chain: every load of the row phase (bulge column, primary and
+// secondary row operands -- none depends on the reflector) is issued in one batch at the top, every load of the column
+// phase in one batch behind the row stores.  (Left alone, the compiler sinks each sub-pass's loads into its predicated
+// store block: five serialised round trips per iteration.)  The empty asm statements pin the batches.
+template <bool GEN, bool R2, bool C2, class V>
+__device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, const bool first, const bool last,
+                                         const bool top, const double v0, const double v1, const double v2) {
+    constexpr int SR = V::kSR, SC = V::kSC;
+    double a0 = S.bp[0], a1 = S.bp[SR], a2 = S.bp[2 * SR];
+    double x0 = S.rowp[0], x1 = S.rowp[SR], x2 = S.rowp[2 * SR];
+    double* const rp2 = S.rowp + S.d_r;
+    double y0, y1, y2;
+    if (R2) {
+        y0 = rp2[0];
+        y1 = rp2[SR];
+        y2 = rp2[2 * SR];
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(y0), "+v"(y1), "+v"(y2));
+    } else {
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
+    }
+    int Lg = L;
+    if (GEN) {
+        a0 = first ? v0 : a0;
+        a1 = first ? v1 : a1;
+        a2 = first ? v2 : (last ? 0.0 : a2);
+        x2 = last ? 0.0 : x2;
+        if (R2) y2 = last ? 0.0 : y2;
+        // a first step at the top of the window (m == l): column l-1 is outside it (H(l, l-1) = 0).  Below the top
+        // (m > l) column m-1 takes part like any bulge column, which scales H(m, m-1) by (1 - t1) as xLAHQR does
+        Lg = (first && top) ? L - 1 : L;
+    }
+    double t1, t2, t3, u1, u2;
+    larfg3_coeffs(a0, a1, a2, t1, t2, t3, u1, u2);
+    {
+        const double sum = fma(u2, x2, fma(u1, x1, x0));
+        const double n0 = fma(-sum, t1, x0), n1 = fma(-sum, t2, x1), n2 = fma(-sum, t3, x2);
+        if (S.er <= Lg) {
+            S.rowp[0] = n0;
+            S.rowp[SR] = n1;
+            if (!GEN || !last) S.rowp[2 * SR] = n2;
+        }
+    }
+    if (R2) {
+        const double sum = fma(u2, y2, fma(u1, y1, y0));
+        const double n0 = fma(-sum, t1, y0), n1 = fma(-sum, t2, y1), n2 = fma(-sum, t3, y2);
+        if (S.er <= Lg - 32) {
+            rp2[0] = n0;
+            rp2[SR] = n1;
+            if (!GEN || !last) rp2[2 * SR] = n2;
+        }
+    }
+    wave_lds_sync();
+    double c0 = S.colp[0], c1 = S.colp[SC], c2 = S.colp[2 * SC];
+    double* const cp2 = S.colp + S.d_c;
+    double d0, d1, d2;
+    if (C2) {
+        d0 = cp2[0];
+        d1 = cp2[SC];
+        d2 = cp2[2 * SC];
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(d0), "+v"(d1), "+v"(d2));
+    } else {
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2));
+    }
+    if (GEN) {
+        c2 = last ? 0.0 : c2;
+        if (C2) d2 = last ? 0.0 : d2;
+    }
+    {
+        const double sum = fma(u2, c2, fma(u1, c1, c0));
+        const double n0 = fma(-sum, t1, c0), n1 = fma(-sum, t2, c1), n2 = fma(-sum, t3, c2);
+        if (S.ec0 <= M) {
+            S.colp[0] = n0;
+            S.colp[SC] = n1;
+            if (!GEN || !last) S.colp[2 * SC] = n2;
+        }
+    }
+    if (C2) {
+        const double sum = fma(u2, d2, fma(u1, d1, d0));
+        const double n0 = fma(-sum, t1, d0), n1 = fma(-sum, t2, d1), n2 = fma(-sum, t3, d2);
+        if (S.ec1 <= M) {
+            cp2[0] = n0;
+            cp2[SC] = n1;
+            if (!GEN || !last) cp2[2 * SC] = n2;
+        }
+    }
+    wave_lds_sync();
+    S.rowp += (GEN && last) ? 0 : S.inc_r;         // a group parks where its last step left it (addresses stay valid)
+    S.colp += (GEN && last) ? 0 : S.inc_c;
+    S.bp += (GEN && (first || last)) ? 0 : S.inc_b;   // bp starts at &H(m+1, m): the first step does not read the bulge
+}
+
+// steady-state iterations t0 <= t < t1 of one (R2, C2) segment: L = Lbase - t, M = Mbase + t
+template <bool R2, bool C2, class V>
+__device__ __forceinline__ void qr2_segment(Qr2Lane& S, int t0, const int t1, const int Lbase, const int Mbase) {
+    for (int t = t0; t < t1; ++t) qr2_iter<false, R2, C2, V>(S, Lbase - t, Mbase + t, false, false, false, 0.0, 0.0, 0.0);
+}
+
+// One sweep over the window [l, i] from start row m with start vector (v0, v1, v2); (rt1r, rt1i, rt2r, rt2i) are the
+// shifts, needed again for the trailing bulge's start vector.
+template <class V>
+__device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, const int m, const int lane, double v0,
+                                          double v1, double v2, const double rt1r, const double rt1i, const double rt2r,
+                                          const double rt2i) {
+    constexpr int SR = V::kSR, SC = V::kSC;
+    const int g = lane >> 5, j = lane & 31;
+    const bool two = (m == l);
+    const int nA = i - m;                                   // steps of one bulge: k = m .. i-1
+    const int T = nA + (two ? kBulgeDist : 0);
+    const int c1 = max(i - 31 + j, 0), c0 = max(i - 63 + j, 0);
+    const int r0 = min(l + j, 63), r1 = min(l + 32 + j, 63);
+    Qr2Lane S;
+    S.rowp = &H.at(m, c1);
+    S.colp = &H.at(r0, m);
+    S.bp = &H.at(m + 1, m);
+    S.d_r = (c0 - c1) * SC;
+    S.d_c = (r1 - r0) * SR;
+    const int er_live = 31 - j - kBulgeDist * g;
+    const int ec0_live = (l + j <= i) ? j + kBulgeDist * g : kNever;
+    const int ec1_live = (l + 32 + j <= i) ? j + 32 + kBulgeDist * g : kNever;
+    const bool liveA = g == 0;
+    S.er = liveA ? er_live : kNever;
+    S.ec0 = liveA ? ec0_live : kNever;
+    S.ec1 = liveA ? ec1_live : kNever;
+    S.inc_r = liveA ? SR : 0;
+    S.inc_c = liveA ? SC : 0;
+    S.inc_b = liveA ? SR + SC : 0;
+    // thresholds of iteration t:  L = i - (m + t) + 1 = Lbase - t,  M = m + t + 3 - l = Mbase + t
+    const int Lbase = nA + 1, Mbase = m + 3 - l;
+    const int tR = Lbase - 28 + 1;                          // R2 holds for t < tR   (L >= 28)
+    const int tC = 32 - Mbase;                              // C2 holds for t >= tC  (M >= 32)
+    // the iterations in which a group starts or ends (at most four, in increasing order of t)
+    const int tLastA = nA - 1, tFirstB = two ? kBulgeDist : T, tLastB = two ? nA - 1 + kBulgeDist : T;
+    int t = 0;
+    while (t < T) {
+        // next special iteration at or after t
+        int tg = tLastB;
+        if (tLastA >= t) tg = min(tg, tLastA);
+        if (tFirstB >= t) tg = min(tg, tFirstB);
+        if (t == 0) tg = 0;
+        // steady-state iterations t .. tg-1, cut into segments of constant (R2, C2)
+        while (t < tg) {
+            const bool r2 = t < tR, c2 = t >= tC;
+            int e = tg;
+            if (r2) e = min(e, tR);
+            if (!c2) e = min(e, tC);
+            if (r2) {
+                if (c2) qr2_segment<true, true, V>(S, t, e, Lbase, Mbase);
+                else qr2_segment<true, false, V>(S, t, e, Lbase, Mbase);
+            } else {
+                if (c2) qr2_segment<false, true, V>(S, t, e, Lbase, Mbase);
+                else qr2_segment<false, false, V>(S, t, e, Lbase, Mbase);
+            }
+            t = e;
+        }
+        if (t >= T) break;
+        const bool fA = t == 0, lA = t == tLastA, fB = t == tFirstB, lB = t == tLastB;
+        if (fB) {
+            // the trailing bulge starts at row m on the matrix as the leading bulge left it (its rows m..m+2 and
+            // columns m, m+1 are final after three steps); same formula as the start search of hqr_wave
+            const double hmm = H.at(m, m), hm1m = H.at(m + 1, m), hm1m1 = H.at(m + 1, m + 1);
+            double s = fabs(hmm - rt2r) + fabs(rt2i) + fabs(hm1m);
+            double rs = fast_rcp(s);
+            const double h21s = hm1m * rs;
+            v0 = h21s * H.at(m, m + 1) + (hmm - rt1r) * ((hmm - rt2r) * rs) - rt1i * (rt2i * rs);
+            v1 = h21s * (hmm + hm1m1 - rt1r - rt2r);
+            v2 = h21s * H.at(m + 2, m + 1);
+            s = fabs(v0) + fabs(v1) + fabs(v2);
+            rs = fast_rcp(s);
+            v0 *= rs;
+            v1 *= rs;
+            v2 *= rs;
+            S.er = liveA ? S.er : er_live;
+            S.ec0 = liveA ? S.ec0 : ec0_live;
+            S.ec1 = liveA ? S.ec1 : ec1_live;
+            S.inc_r = liveA ? S.inc_r : SR;
+            S.inc_c = liveA ? S.inc_c : SC;
+            S.inc_b = liveA ? S.inc_b : SR + SC;
+        }
+        {
+            const bool first = liveA ? fA : fB, last = liveA ? lA : lB;
+            // the special iterations always run both secondary sub-passes (validity masks decide, correctness does not
+            // depend on the R2 / C2 shortcut)
+            qr2_iter<true, true, true, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
+            const bool park = last;
+            S.er = park ? kNever : S.er;
+            S.ec0 = park ? kNever : S.ec0;
+            S.ec1 = park ? kNever : S.ec1;
+            S.inc_r = park ? 0 : S.inc_r;
+            S.inc_c = park ? 0 : S.inc_c;
+            S.inc_b = park ? 0 : S.inc_b;
+        }
+        ++t;
+    }
+}
+
 template <class V>
 __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
                          int32_t* __restrict__ info_out, const double rescale) {
@@ -689,7 +945,12 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
             v1 = bcast_lane(v1, m);
             v2 = bcast_lane(v2, m);
 
-            // ---- double-shift QR sweep: chase the bulge from row m to row i (m <= i-2) ----
+            // ---- double-shift QR sweep: chase the bulge(s) from row m to row i (m <= i-2) ----
+#ifndef EGS_QR_SINGLE_BULGE
+            if constexpr (V::kFast) {
+                qr2_sweep(H, l, i, m, lane, v0, v1, v2, rt1r, rt1i, rt2r, rt2i);
+            } else
+#endif
             {
                 double a0 = v0, a1 = v1, a2 = v2;
                 double* rowp = &H.at(m, lane);
@@ -944,7 +1205,9 @@ int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* in
         if (v >= 1 && v <= 4 && (size_t)v * pair_bytes <= 160 * 1024) pairs = v;
     }
     const int hqr_waves = 2 * pairs;
-    const size_t hqr_lds = pairs * pair_bytes;
+    // + 1 KB: the order-2 step at the bottom of a 64-row window addresses row / column 64 of its (unused) third operand,
+    // up to 70 doubles past the last pair array; reads only, the values are discarded
+    const size_t hqr_lds = pairs * pair_bytes + 1024;
     unsigned gq = (unsigned)((nmat + hqr_waves - 1) / hqr_waves);
     if (queue != nullptr && !getenv("EGS_HQR_NONPERSISTENT")) {   // one resident wave set + work queue
         const int cus = current_device_cus();

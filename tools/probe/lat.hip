@@ -22,8 +22,9 @@ __device__ __forceinline__ double dpp_mov(double x) {
 }
 
 __global__ void lat(double* out, const double* in, int sidx, double* sink) {
-    __shared__ double lds[1024];
-    const int lane = threadIdx.x;
+    __shared__ double lds_all[8 * 1024];
+    const int lane = threadIdx.x & 63;              // every wave runs the same chains on its own 8 KB of LDS
+    double* lds = lds_all + (threadIdx.x >> 6) * 1024;
     double a = in[lane], b = in[64 + lane], c = in[128 + lane];
     for (int i = lane; i < 1024; i += 64) lds[i] = in[i & 255];
     __syncthreads();
@@ -245,7 +246,7 @@ __global__ void lat(double* out, const double* in, int sidx, double* sink) {
         T1(21);
         acc += x;
     }
-    sink[blockIdx.x * blockDim.x + lane] = acc;
+    sink[threadIdx.x] = acc;   // 512 threads at most, 4096 slots
 }
 
 int main() {

@@ -1,0 +1,18 @@
+# PMC passes over tools/time_c2.py (fused n = 64 kernel only).  Summaries land in gpurun_out/c2prof/.
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/c2prof
+mkdir -p $O
+export NMAT=${NMAT:-131072} KIND=${KIND:-s5} REPS=3
+CMD="python3 $R/tools/time_c2.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o run -- $CMD > $O/trace.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU -d $O/pmc1 -o run -- $CMD > $O/pmc1.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc2 -o run -- $CMD > $O/pmc2.log 2>&1
+cd $R
+python3 tools/pmc_summary.py trace $O/trace > $O/kernel_stats.csv
+python3 tools/pmc_summary.py counters $O/pmc1 $O/pmc2 > $O/pmc_counters.json
+find $O -name "*.csv" -size +1M -delete
+grep -h '^{' $O/trace.log || true
+cat $O/kernel_stats.csv
+cat $O/pmc_counters.json
