@@ -553,14 +553,16 @@ __device__ __forceinline__ void qr_step2(const V& H, int k, int l, int i, int la
 //
 // A bulge step is ~22 vector instructions of wave-uniform reflector arithmetic plus two O(n) passes that use the lanes;
 // chasing ONE bulge per wavefront therefore spends most of its issue slots on work that 63 lanes repeat.  Here a sweep
-// chases TWO double-shift bulges, the second kBulgeDist = 4 rows behind the first, and the same instructions serve both:
+// chases TWO double-shift bulges, the second kBulgeDist = 3 rows behind the first, and the same instructions serve both:
 // lanes 0-31 (group 0) work for the leading bulge, lanes 32-63 (group 1) for the trailing one -- every "uniform" quantity
 // (bulge column, reflector, row / column indices) is uniform per half-wave, the row and column operations run as
-// sub-passes of 32 columns / rows per group.  At distance >= 4 the two row operations touch disjoint rows, the two
-// column operations disjoint columns, and no element receives a row operation of one bulge and a column operation of
-// the other in the same pass, so an iteration is (row passes of both) -> (column passes of both) and the result is that
-// of two consecutive sweeps with the same double shift (oracle/hqr2_proto.py restates the iteration and was checked
-// against LAPACK first: 0.66 iterations per single-bulge step on the benchmark's matrices).
+// sub-passes of 32 columns / rows per group.  At distance >= 3 the two row operations touch disjoint rows (k..k+2 and
+// k-3..k-1) and the two column operations disjoint columns, so within a pass every element has one writer; an element
+// that receives a row operation of one bulge and a column operation of the other gets them in successive passes, and
+// left and right multiplications commute.  An iteration is (row passes of both) -> (column passes of both) and the result
+// is that of two consecutive sweeps with the same double shift (oracle/hqr2_proto.py restates the iteration,
+// tools/qr2_lane_model.py the lane / pointer / validity bookkeeping below with write-overlap assertions; both were checked
+// against LAPACK before the kernel ran: 0.66 iterations per single-bulge step on the benchmark's matrices).
 //
 // Other differences from qr_step3: (1) the bulge column is read back from LDS at the top of an iteration (three
 // broadcast reads per group) instead of six v_readlane; (2) it is not overwritten with (beta, 0, 0): column k-1 simply
@@ -571,7 +573,10 @@ __device__ __forceinline__ void qr_step2(const V& H, int k, int l, int i, int la
 // increments and validity is one compare of a per-lane constant with a wave-uniform counter per sub-pass.
 // Sweeps whose start row m lies below the top of the window (m > l, ~7 %) chase a single bulge (group 1 stays parked).
 // ---------------------------------------------------------------------------------------------------
-constexpr int kBulgeDist = 4;
+#ifndef EGS_QR2_DIST
+#define EGS_QR2_DIST 3
+#endif
+constexpr int kBulgeDist = EGS_QR2_DIST;   // rows between the two bulges (>= 3: see below)
 constexpr int kNever = 1 << 20;               // validity constant of a lane that must not store
 
 // Reflector of the bulge column (a0; a1, a2) without beta.  nrm carries +1e-300 so that an all-zero column gives
@@ -735,7 +740,7 @@ __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, 
     S.inc_b = liveA ? SR + SC : 0;
     // thresholds of iteration t:  L = i - (m + t) + 1 = Lbase - t,  M = m + t + 3 - l = Mbase + t
     const int Lbase = nA + 1, Mbase = m + 3 - l;
-    const int tR = Lbase - 28 + 1;                          // R2 holds for t < tR   (L >= 28)
+    const int tR = Lbase - (32 - kBulgeDist) + 1;            // R2 holds for t < tR   (L >= 32 - kBulgeDist: group 1, lane 31)
     const int tC = 32 - Mbase;                              // C2 holds for t >= tC  (M >= 32)
     // the iterations in which a group starts or ends (at most four, in increasing order of t)
     const int tLastA = nA - 1, tFirstB = two ? kBulgeDist : T, tLastB = two ? nA - 1 + kBulgeDist : T;

@@ -11,7 +11,7 @@ from oracle import hqr2_proto as P2, hqr_proto as P1  # noqa: E402
 import oracle as O  # noqa: E402
 
 NEVER = 1 << 20
-DIST = 4
+DIST = int(__import__("os").environ.get("QR2_DIST", 4))
 PAD = 80
 
 
