@@ -261,9 +261,11 @@ def main():
     }
 
     # ---- HBM-bound kernels of the same path (north_star: >= 40 % of HBM peak on the scan kernels), timed live ----
-    secondary = None
+    secondary, headline = None, None
     if rank == 0 and world == 1:
         secondary = stream_rooflines(ops, device)
+        if not args.no_cpu:
+            headline = mqar_headline(ops, device)
 
     # ---- parity: GPU spectra vs the known spectrum and vs LAPACK on a sample ----
     info_bad = int((info != 0).sum().item())
@@ -287,7 +289,7 @@ def main():
                        "parallelism": "matrix-sharded x%d, one all_gather of spectra" % world},
             "max_abs_dlambda_vs_lapack": d_lapack, "max_abs_dlambda_vs_known": d_known, "unconverged": info_bad,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_pool": cpu_multi,
-            "secondary_rooflines": secondary,
+            "secondary_rooflines": secondary, "north_star_mqar_batch": headline,
             # what the process group actually looked like (so a SCALE record shows that RCCL saw N ranks on N devices)
             "world": world, "dist_backend": backend if world > 1 else None,
             "visible_devices": torch.cuda.device_count(), "device_name": torch.cuda.get_device_name(device),
@@ -460,6 +462,60 @@ def stream_rooflines(ops, device):
                            "zmsqr_kernel": {"ms": qr_ms, "achieved_tflops": tf_q, "frac": tf_q / FP64_PEAK_TFLOPS}},
                 "note": "fp64 (matrix = vector peak); algorithmic flops 4 x (40/3) n^3 per matrix (Hessenberg 4 x (10/3) "
                         "n^3, QR 4 x 10 n^3); HIP events on the launch stream, median of 3"})
+    return out
+
+
+def mqar_headline(ops, device):
+    """north_star's own headline: a 4096-sequence MQAR analysis batch (L = 512, hidden 128, d_state = d_qk = 64, 1 head;
+    configs/iclr2026/mqar/mqar-{lin,sm}-attention.yaml:6, analysis_configs/mqar_analysis_config.yaml:1) through the GPU
+    path -- eta kernels + device histogram + the D2H copy the artefacts need, wall clock -- next to the reference-style
+    CPU path: the oracle's quadratic (B, L, L, H) restatement of analysis/eval_eig.py:43-135 timed on 64 sequences (the
+    reference's own analysis batch) on ONE host core and scaled linearly in B (labelled as extrapolated)."""
+    import oracle as O
+    B, L, D, dqk, H, nb = 4096, 512, 128, 64, 1, 64
+    g = torch.Generator(device=device)
+    g.manual_seed(1919)
+    x = torch.randn((B, L, D), generator=g, device=device)
+    w = (torch.rand((2 * dqk + D, D), generator=g, device=device) * 2 - 1) / np.sqrt(D)
+    b = (torch.rand((2 * dqk + D,), generator=g, device=device) * 2 - 1) / np.sqrt(D)
+    wq, bq = w[:2 * dqk].contiguous(), b[:2 * dqk].contiguous()
+    xs, ws, bs = x[:nb].cpu().numpy(), w.cpu().numpy(), b.cpu().numpy()
+    out = {"workload": "MQAR analysis batch: B=4096 sequences, L=512, hidden 128, d_state=d_qk=64, 1 head",
+           "gpu_timed": "eta kernels + threshold histogram on the device + D2H copy of eta and percentages (median of 3)",
+           "cpu_timed": "oracle eta_linear / eta_softmax (quadratic NumPy form) + threshold_analysis on %d sequences, "
+                        "1 process; extrapolated linearly in B to 4096" % nb}
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:
+        limiter = None
+    for name, gpu_fn, cpu_fn in (("lin-attention", ops.linattn_eta, O.eta_linear),
+                                 ("sm-attention", ops.softmax_eta, O.eta_softmax)):
+        gpu_fn(x, wq, bq, dqk, H)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            eta = gpu_fn(x, wq, bq, dqk, H)
+            pct = ops.threshold_hist(eta.unsqueeze(-1), O.THRESHOLDS_RADIUS, "value")
+            eta_h, pct_h = eta.cpu().numpy(), pct.cpu().numpy()
+            ts.append(time.perf_counter() - t0)
+        t_gpu = float(np.median(ts))
+        t0 = time.perf_counter()
+        ref = cpu_fn(xs, ws, bs, dqk, H, D)
+        refp = O.threshold_analysis(ref, O.THRESHOLDS_RADIUS, 1, H, nb)
+        t_cpu = time.perf_counter() - t0
+        out[name] = {
+            "gpu_s": t_gpu, "gpu_sequences_per_s": B / t_gpu,
+            "cpu_baseline": {"value": nb / t_cpu, "unit": "sequences/s", "cores": 1, "kind": "port",
+                             "sample": "%d of the batch's own sequences, %.2f s" % (nb, t_cpu),
+                             "extrapolated_full_batch_s": t_cpu * B / nb},
+            "speedup_vs_cpu_extrapolated": (t_cpu * B / nb) / t_gpu,
+            "max_rel_err_vs_oracle_on_sample": float(np.max(np.abs(eta_h[:nb] / ref[..., 0] - 1))),
+            "hist_max_abs_diff_pct_on_sample": float(np.max(np.abs(pct_h[:, :nb].reshape(refp[..., 0].shape) - refp[..., 0]))),
+        }
+    if limiter is not None and hasattr(limiter, "unregister"):
+        limiter.unregister()
     return out
 
 

@@ -345,6 +345,29 @@ def test_linear_attention_fused_path(gpu_ops, monkeypatch, heads, seqlen):
     np.testing.assert_allclose(got, ref, rtol=1e-9)          # same fp32 projection bit for bit, fp64 sums in another order
 
 
+@pytest.mark.parametrize("heads", [1, 2])
+def test_linear_attention_fused_kernel_at_the_c4_shard_shape(gpu_ops, monkeypatch, heads):
+    """BASELINE config C4's own shape on the kernel that serves it: B = 128 (the fused kernel's threshold), L = 4096,
+    D = 128, d_qk = 128 -- 32 tiles of register-carried prefix state per sequence.  First and last three sequences
+    against the O(L) float64 oracle, the whole batch against the two-kernel path."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4096 + heads)
+    bsz, seqlen, d, d_qk = 128, 4096, 128, 128
+    x = torch.randn((bsz, seqlen, d), generator=g, device="cuda")
+    w = (torch.rand((2 * d_qk + d, d), generator=g, device="cuda") * 2 - 1) / np.sqrt(d)
+    b = (torch.rand((2 * d_qk + d,), generator=g, device="cuda") * 2 - 1) / np.sqrt(d)
+    got = gpu_ops.linattn_eta(x, w[:2 * d_qk].contiguous(), b[:2 * d_qk].contiguous(), d_qk, heads)
+    assert got.shape == (bsz, seqlen - 1, heads) and bool(torch.isfinite(got).all()) and bool((got > 0).all())
+    pick = [0, 1, 2, bsz - 3, bsz - 2, bsz - 1]
+    want = O.eta_linear_streaming(x[pick].cpu().numpy(), w.cpu().numpy(), b.cpu().numpy(), d_qk, heads, d)[..., 0]
+    np.testing.assert_allclose(got[pick].cpu().numpy(), want, rtol=1e-5)
+    monkeypatch.setenv("EGS_LINATTN_UNFUSED", "1")
+    ref = gpu_ops.linattn_eta(x, w[:2 * d_qk].contiguous(), b[:2 * d_qk].contiguous(), d_qk, heads)
+    monkeypatch.delenv("EGS_LINATTN_UNFUSED")
+    err = float(((got - ref).abs() / ref.abs()).max().item())
+    assert err < 1e-9, err                                   # same fp32 projection bit for bit, fp64 sums in another order
+
+
 @pytest.mark.parametrize("seqlen,d_qk,h", [(70, 16, 2), (300, 128, 1), (513, 192, 3)])
 def test_linear_attention_eta_from_existing_qk(gpu_ops, seqlen, d_qk, h):
     """The (q, k)-input entry point (raw projections in, elu + 1 applied on the device) against the x-input path fed

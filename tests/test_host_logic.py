@@ -405,3 +405,24 @@ def test_bench_gpus_flag_starts_that_many_ranks():
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     out, lines = _bench_lines(["--gpus", "4", "--rehearse-launch"], env={"WORLD_SIZE": "2", "RANK": "0"})
     assert out.returncode != 0 and not lines and "--gpus 4" in (out.stderr + out.stdout)
+
+
+@pytest.mark.parametrize("kind", ["lru", "s4", "s5"])
+def test_numpy_ssm_init_agrees_with_the_independent_oracle(pkg, kind):
+    """The product's JAX-free initial parameters (analysis/jax_prng.py, vectorised NumPy) against the oracle's own
+    restatement of the same draw (oracle/ssm_init_oracle.py, scalar integers, separate key bookkeeping): bit for bit.
+    Both restate jax 0.4.25 / flax 0.8.1 from their published sources; what pins them to jax itself is the Threefry
+    known answers and jax's documented PRNGKey(0) examples (checked for both implementations)."""
+    from oracle import ssm_init_oracle as SI
+    ev = sys.modules[pkg.__name__ + ".analysis.eval_eig"]
+    cfg = {"state_dim": 16, "hidden_dim": 5, "num_layers": 3, "num_blocks": 2, "r_min": 0.4, "r_max": 0.99,
+           "max_phase": 3.14, "dt_min": 0.002, "dt_max": 0.2}
+    got, want = ev.init_layers_ssm_numpy(kind, 1919, cfg), SI.init_layers(kind, 1919, cfg)
+    assert len(got) == len(want) == 3
+    for a, b in zip(got, want):
+        assert sorted(a) == sorted(b)
+        for name in a:
+            assert np.asarray(a[name]).dtype == np.asarray(b[name]).dtype and np.array_equal(a[name], b[name]), (kind, name)
+    assert SI.threefry2x32_pair(0x13198A2E, 0x03707344, 0x243F6A88, 0x85A308D3) == (0xC4923A9C, 0x483DF7A0)
+    assert SI.split(SI.key_of(0)) == [(4146024105, 967050713), (2718843009, 1272950319)]
+    assert abs(float(SI.uniform32(SI.key_of(0), 1)[0]) - 0.41845703) < 1e-8

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""profiles/rNN_traffic.json from the PMC summary of tools/prof_bench.sh (gpurun_out/benchprof/pmc_counters.json).
+
+HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (counters are KB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B,
+so the read side is doubled -- MI355X_MICROARCH.md, HBM section), summed over the launches of a kernel and divided by
+their number.  For the eigenvalue kernels the file also records the matrices per launch, the bytes per matrix and the
+sha256 of the kernel's source files (bench.kernel_source_sha): bench.py quotes the traffic only while that hash matches
+the library it runs, so a stale measurement can never be reported for a changed kernel.
+    python tools/make_traffic.py gpurun_out/benchprof/pmc_counters.json r03 [nmat_per_launch]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    nmat = int(sys.argv[3]) if len(sys.argv) > 3 else 524288
+    import bench
+    pmc = json.load(open(src))
+    out = {"method": __doc__.split("\n\n")[1].replace("\n", " "), "source_pmc": src, "kernels": {}}
+    algo = {"eig_real64_kernel": (64 * 64 * 8 + 16 * 64 + 4) * nmat}
+    for name, c in sorted(pmc.items()):
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        n = max(1, int(c.get("launches", 1)))
+        fetch = c["FETCH_SIZE"] * 1024.0 / n
+        write = c["WRITE_SIZE"] * 1024.0 / n
+        short = name.replace("egs::", "")
+        ent = {"launches": n, "fetch_bytes_raw": fetch, "write_bytes": write, "fetch_correction": 2.0,
+               "hbm_bytes_per_launch": 2.0 * fetch + write}
+        base = short.split("<")[0]
+        if base in bench.KERNEL_SOURCES:
+            ent["source_sha"] = bench.kernel_source_sha(base)
+        if base in algo:
+            ent["matrices_per_launch"] = nmat
+            ent["hbm_bytes_per_matrix"] = ent["hbm_bytes_per_launch"] / nmat
+            ent["algorithmic_bytes_per_launch"] = algo[base]
+            ent["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / algo[base]
+        out["kernels"][short] = ent
+    dst = os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)
+    json.dump(out, open(dst, "w"), indent=1)
+    print("wrote", dst, "with", len(out["kernels"]), "kernels")
+
+
+if __name__ == "__main__":
+    main()
