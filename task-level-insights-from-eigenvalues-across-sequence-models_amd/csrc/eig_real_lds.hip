@@ -792,9 +792,14 @@ __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, 
         }
         {
             const bool first = liveA ? fA : fB, last = liveA ? lA : lB;
-            // the special iterations always run both secondary sub-passes (validity masks decide, correctness does not
-            // depend on the R2 / C2 shortcut)
-            qr2_iter<true, true, true, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
+            const bool r2 = t < tR, c2 = t >= tC;
+            if (r2) {
+                if (c2) qr2_iter<true, true, true, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
+                else qr2_iter<true, true, false, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
+            } else {
+                if (c2) qr2_iter<true, false, true, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
+                else qr2_iter<true, false, false, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
+            }
             const bool park = last;
             S.er = park ? kNever : S.er;
             S.ec0 = park ? kNever : S.ec0;
