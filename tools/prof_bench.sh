@@ -3,7 +3,7 @@
 # kernel trace + stats, SQ counters, FETCH_SIZE, WRITE_SIZE.  Summaries land in gpurun_out/benchprof/.
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/benchprof
 mkdir -p $O
 CMD="python3 $R/bench.py --no-cpu"

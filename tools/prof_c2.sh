@@ -1,7 +1,7 @@
 # PMC passes over tools/time_c2.py (fused n = 64 kernel only).  Summaries land in gpurun_out/c2prof/.
 set -e
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/c2prof
 mkdir -p $O
 export NMAT=${NMAT:-131072} KIND=${KIND:-s5} REPS=3
