@@ -595,6 +595,23 @@ __device__ __forceinline__ void larfg3_coeffs(double a0, double a1, double a2, d
     t3 = t1 * u2;
 }
 
+// Predicated store of three doubles p[0], p[S1], p[2 S1] by the lanes with e <= thr (thr wave-uniform): v_cmpx writes
+// EXEC directly, the stores run under it, EXEC goes back to all ones -- two instructions of overhead instead of the
+// compare + s_and_saveexec + s_cbranch_execz + s_or the compiler emits for `if (e <= thr) { ... }`, and no branch.
+// Only used where control flow is wave-uniform with all 64 lanes alive (the steady-state iterations of a sweep).
+template <int S1>
+__device__ __forceinline__ void lds_store3_where_le(int e, int thr, double* p, double v0, double v1, double v2) {
+    static_assert(2 * S1 < 256, "ds_write2_b64 offsets are 8-bit, in units of 8 bytes");
+    asm volatile(
+        "v_cmpx_ge_i32_e32 vcc, %1, %0\n\t"
+        "ds_write2_b64 %2, %3, %4 offset1:%6\n\t"
+        "ds_write_b64 %2, %5 offset:%7\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : "v"(e), "s"(thr), "v"((unsigned)(uintptr_t)p), "v"(v0), "v"(v1), "v"(v2), "n"(S1), "n"(2 * S1 * 8)
+        : "vcc", "memory");
+}
+
 struct Qr2Lane {
     double* rowp;      // &H(k, c1): this lane's primary column of the row operation, at the group's bulge row k
     double* colp;      // &H(r0, k): this lane's primary row of the column operation
@@ -648,19 +665,23 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, c
     {
         const double sum = fma(u2, x2, fma(u1, x1, x0));
         const double n0 = fma(-sum, t1, x0), n1 = fma(-sum, t2, x1), n2 = fma(-sum, t3, x2);
-        if (S.er <= Lg) {
+        if (!GEN) {
+            lds_store3_where_le<SR>(S.er, Lg, S.rowp, n0, n1, n2);
+        } else if (S.er <= Lg) {
             S.rowp[0] = n0;
             S.rowp[SR] = n1;
-            if (!GEN || !last) S.rowp[2 * SR] = n2;
+            if (!last) S.rowp[2 * SR] = n2;
         }
     }
     if (R2) {
         const double sum = fma(u2, y2, fma(u1, y1, y0));
         const double n0 = fma(-sum, t1, y0), n1 = fma(-sum, t2, y1), n2 = fma(-sum, t3, y2);
-        if (S.er <= Lg - 32) {
+        if (!GEN) {
+            lds_store3_where_le<SR>(S.er, Lg - 32, rp2, n0, n1, n2);
+        } else if (S.er <= Lg - 32) {
             rp2[0] = n0;
             rp2[SR] = n1;
-            if (!GEN || !last) rp2[2 * SR] = n2;
+            if (!last) rp2[2 * SR] = n2;
         }
     }
     wave_lds_sync();
@@ -682,19 +703,23 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, c
     {
         const double sum = fma(u2, c2, fma(u1, c1, c0));
         const double n0 = fma(-sum, t1, c0), n1 = fma(-sum, t2, c1), n2 = fma(-sum, t3, c2);
-        if (S.ec0 <= M) {
+        if (!GEN) {
+            lds_store3_where_le<SC>(S.ec0, M, S.colp, n0, n1, n2);
+        } else if (S.ec0 <= M) {
             S.colp[0] = n0;
             S.colp[SC] = n1;
-            if (!GEN || !last) S.colp[2 * SC] = n2;
+            if (!last) S.colp[2 * SC] = n2;
         }
     }
     if (C2) {
         const double sum = fma(u2, d2, fma(u1, d1, d0));
         const double n0 = fma(-sum, t1, d0), n1 = fma(-sum, t2, d1), n2 = fma(-sum, t3, d2);
-        if (S.ec1 <= M) {
+        if (!GEN) {
+            lds_store3_where_le<SC>(S.ec1, M, cp2, n0, n1, n2);
+        } else if (S.ec1 <= M) {
             cp2[0] = n0;
             cp2[SC] = n1;
-            if (!GEN || !last) cp2[2 * SC] = n2;
+            if (!last) cp2[2 * SC] = n2;
         }
     }
     wave_lds_sync();
@@ -1035,6 +1060,10 @@ __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ sr
     hqr_wave(H, n, lane, wo, info, rescale);
 }
 
+// N64 = true: n == 64, only the two compile-time layouts (two-bulge sweep); false: any n < 64 (run-time leading dimension,
+// single-bulge sweep).  Two kernels instead of four inlined copies of hqr_wave in one: the scalar state of each fits
+// the SGPR file (the single kernel of rounds 1-2 spilled 257 SGPRs).
+template <bool N64>
 __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
                                                        double* __restrict__ w, int32_t* __restrict__ info,
                                                        int waves_per_block, int scaled,
@@ -1062,7 +1091,7 @@ __global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict_
             if (lane == 0) info[mat] = n;
         } else {
         const double rescale = scaled ? scalbn(1.0, info[mat]) : 1.0;
-        if (n == 64) {
+        if constexpr (N64) {
             if ((wave & 1) == 0) hqr_run(MatViewT<kLd64, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
             else hqr_run(MatViewT<kLd64, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
         } else {
@@ -1172,7 +1201,9 @@ size_t eig_real_lds_workspace_bytes(int64_t nmat, int n) {
 static int set_lds_attrs() {
     EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hess_real_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hqr_real_kernel),
+    EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hqr_real_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hqr_real_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return 0;
 }
@@ -1231,8 +1262,12 @@ int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* in
     } else {
         queue = nullptr;
     }
-    hipLaunchKernelGGL(hqr_real_kernel, dim3(gq), dim3(hqr_waves * kWave), hqr_lds, stream, h, nmat, n, w, info,
-                       hqr_waves, scaled, queue);
+    if (n == 64)
+        hipLaunchKernelGGL(hqr_real_kernel<true>, dim3(gq), dim3(hqr_waves * kWave), hqr_lds, stream, h, nmat, n, w, info,
+                           hqr_waves, scaled, queue);
+    else
+        hipLaunchKernelGGL(hqr_real_kernel<false>, dim3(gq), dim3(hqr_waves * kWave), hqr_lds, stream, h, nmat, n, w, info,
+                           hqr_waves, scaled, queue);
     EGS_LAUNCH_CHECK();
     return 0;
 }
