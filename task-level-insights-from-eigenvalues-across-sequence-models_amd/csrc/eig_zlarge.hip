@@ -742,6 +742,130 @@ __device__ __forceinline__ void zchase3(zq* __restrict__ Wn, zq* __restrict__ Un
 #undef CSTAMP
 }
 
+// zchase3 for the INTERIOR stages of a sweep -- every one of the 16 bulges is inside the window for every step of the
+// stage, none is being introduced and none leaves the active block:
+//     t0 >= 2 (QM - 1) + 1,   l + t1 + 3 <= i,   s = l + t0 - 2 (QM - 1) - 1,   wd = QW,
+// so bulge b sits at window row pw = 2 (QM - 1) + 1 - 2 b + (t - t0) and every flag of the general routine (act, intro,
+// ahead, bl_lane, the clamps of pw, rmaxw, wd) is a constant.  The general body issues ~400 instructions per wave and
+// step, 73 of them fp64 arithmetic; with four waves per SIMD the chase is bound by exactly that count (16 waves x
+// instructions per step / 4 SIMDs ~ the 3,250 cycles a step was measured at).  This body keeps the protocol of zchase3
+// (prm / mbx tables double-buffered by step parity, look-ahead by lanes 0..3 of waves 0..3) and drops everything else:
+// pointers advance by constants, U's shared column stays in a register for the whole stage, and the annihilated bulge
+// column goes through the row rotation like every other column (lane pw-1 stores (rho~, eps) instead of a selected
+// (rho, 0): rounding-level entries below the sub-diagonal, which the next rotation of that column absorbs).
+#ifdef EGS_ZCHASE_STAMPS
+constexpr bool kZSteadyStamps = true;
+#else
+constexpr bool kZSteadyStamps = false;
+#endif
+template <bool PROF>
+__device__ __forceinline__ void zchase3_steady(zq* __restrict__ Wn, zq* __restrict__ Un, zq* __restrict__ prm,
+                                               zq* __restrict__ mbx, int t0, int t1, int lane, int wv,
+                                               long long (&cst)[4]) {
+    long long tl = PROF ? (long long)__builtin_readcyclecounter() : 0;
+#define SSTAMP(k)                                                  \
+    if (PROF) {                                                    \
+        const long long now_ = __builtin_readcyclecounter();       \
+        cst[k] += now_ - tl;                                       \
+        tl = now_;                                                 \
+    }
+    constexpr int P0 = 2 * (QM - 1) + 1;                               // window row of bulge 0 at step t0
+    const int bg = 4 * (wv & 3) + (lane & 3);                          // look-ahead lane -> bulge
+    const bool lwave = wv < 4;
+    if (lwave) {                                                       // rotations of step t0 from the window
+        const int pc = P0 - 2 * bg;
+        double c;
+        zq sn, rho;
+        zgivens(Wn[pc * QLD + pc - 1], Wn[(pc + 1) * QLD + pc - 1], c, sn, rho);
+        if (lane < 4) {
+            prm[((t0 & 1) * QM + bg) * 3 + 0] = {c, 0.0};
+            prm[((t0 & 1) * QM + bg) * 3 + 1] = sn;
+            prm[((t0 & 1) * QM + bg) * 3 + 2] = rho;
+            if (bg + 1 < QM) mbx[((t0 & 1) * QM + bg + 1) * 3 + 2] = rho;
+        }
+    }
+    __syncthreads();
+    const int b = wv;
+    int pw = P0 - 2 * b;
+    zq* rowp = Wn + pw * QLD + lane;                                   // (pw, lane), advances by QLD
+    zq* colp = Wn + lane * QLD + pw;                                   // (lane, pw), advances by 1
+    zq* ucol = Un + lane * QLD + pw;
+    zq ucar = ucol[0];                                                 // column pw of U: carried from step to step
+    for (int t = t0; t <= t1; ++t) {
+        const int par = t & 1;
+        const zq* pr = prm + (par * QM + b) * 3;
+        // ---- phase 1: rows pw, pw+1 of the window (lane = column), mailbox ----
+        const double c = pr[0].re;
+        const zq sn = pr[1];
+        const zq r0 = rowp[0], r1 = rowp[QLD];
+        zq y0, y1;
+        zrot_rows(c, sn, r0, r1, y0, y1);
+        if (lane >= pw - 1) {
+            rowp[0] = y0;
+            rowp[QLD] = y1;
+        }
+        {
+            zq* mb = mbx + (par * QM + b) * 3;
+            if (b == 0) {                                              // nobody in front: the sub-diagonal entry itself
+                const zq bl = Wn[(pw + 2) * QLD + pw + 1];
+                const zq v = qsel(lane == pw + 2, bl, y1);
+                if (lane >= pw && lane < pw + 3) mb[lane - pw] = v;
+            } else {
+                if (lane >= pw && lane < pw + 2) mb[lane - pw] = y1;
+            }
+        }
+        SSTAMP(0)
+        __syncthreads();
+        SSTAMP(1)
+        // ---- phase 2: columns pw, pw+1 of the window and of U (lane = row); next rotation by the look-ahead lanes ----
+        const zq c0 = colp[0], c1 = colp[1];
+        const zq u1 = ucol[1];
+        if (lwave) {
+            __builtin_amdgcn_s_setprio(3);
+            const zq* lp = prm + (par * QM + bg) * 3;
+            const zq* lm = mbx + (par * QM + bg) * 3;
+            const double lc = lp[0].re;
+            const zq ls = lp[1];
+            const zq x00 = lm[0], x01 = lm[1], x11 = lm[2];
+            const zq a0 = {fma(lc, x00.re, fma(ls.re, x01.re, ls.im * x01.im)), fma(lc, x00.im, fma(ls.re, x01.im, -ls.im * x01.re))};
+            const zq a1 = {fma(ls.re, x11.re, ls.im * x11.im), fma(ls.re, x11.im, -ls.im * x11.re)};
+            double nc;
+            zq nsn, nrho;
+            zgivens(a0, a1, nc, nsn, nrho);
+            if (t < t1 && lane < 4) {
+                zq* np = prm + ((par ^ 1) * QM + bg) * 3;
+                np[0] = {nc, 0.0};
+                np[1] = nsn;
+                np[2] = nrho;
+                if (bg + 1 < QM) mbx[((par ^ 1) * QM + bg + 1) * 3 + 2] = nrho;
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        {
+            zq y0c, y1c;
+            zrot_cols(c, sn, c0, c1, y0c, y1c);
+            if (lane <= pw + 2) {
+                colp[0] = y0c;
+                colp[1] = y1c;
+            }
+            zq v0, v1;
+            zrot_cols(c, sn, ucar, u1, v0, v1);
+            ucol[0] = v0;
+            ucar = v1;
+        }
+        SSTAMP(2)
+        __syncthreads();
+        SSTAMP(3)
+        ++pw;
+        rowp += QLD;
+        colp += 1;
+        ucol += 1;
+    }
+    ucol[0] = ucar;                                                    // column pw(t1) + 1 of U
+    __syncthreads();
+#undef SSTAMP
+}
+
 // Deferred update of one side by the accumulated U (both as  out(f, g) = sum_k X(k, f) U'(k, g)  on the matrix cores):
 //   LEFT = false: rows [f0, f0 + nf) above the window:    H(f0 + f, s + g) <- sum_k H(f0 + f, s + k) U(k, g)
 //   LEFT = true : columns [f0, f0 + nf) right of it:      H(s + g, f0 + f) <- sum_k conj(U(k, g)) H(s + k, f0 + f)
@@ -825,7 +949,8 @@ __device__ __forceinline__ void zapply_u(zq* __restrict__ H, int n, zq* __restri
 // window load + store, chase, deferred updates, single-window chase), the sweep / stage counts, and the split of the
 // chase as wave 0 sees it (row phase, barrier, column phase, barrier).
 __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, int n, double* __restrict__ w,
-                                                    int32_t* __restrict__ info_out, double* __restrict__ prof) {
+                                                    int32_t* __restrict__ info_out, double* __restrict__ prof,
+                                                    int zgeneral_only) {
     extern __shared__ __attribute__((aligned(16))) double dynq[];
     __shared__ int s_idx;
     __shared__ int32_t s_info;
@@ -983,7 +1108,12 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
             __syncthreads();
             ZSTAMP(pacc2)
             ++nstage;
-            zchase3<true>(Wn, Un, prm, mbx, shifts, s, wd, l, i, t0, t1, lane, wv, prof != nullptr, cst);
+            if (t0 >= 2 * (QM - 1) + 1 && l + t1 + 3 <= i && wd == QW && !zgeneral_only) {
+                // (EGS_ZCHASE_STAMPS builds stamp this body too: 26.2 against 29.8 Mcycles of chase per C5 matrix,
+                // profiles/r03_c5_phase_cycles.json)
+                zchase3_steady<kZSteadyStamps>(Wn, Un, prm, mbx, t0, t1, lane, wv, cst);
+            } else
+                zchase3<true>(Wn, Un, prm, mbx, shifts, s, wd, l, i, t0, t1, lane, wv, prof != nullptr, cst);
             ZSTAMP(pacc3)
             for (int e = tid; e < QW * QW; e += kZL) {
                 const int c = e >> 6, r = e & 63;
@@ -1053,8 +1183,9 @@ int zmsqr_launch(int64_t nmat, int n, double* w, int32_t* info, void* workspace,
     const size_t dyn = ((size_t)2 * QW * QLD + QSMALL * QSLD + QM + QSMALL + 6 * QM + 6 * QM) * sizeof(zq);
     EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zmsqr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dyn));
+    const int general_only = getenv("EGS_ZCHASE_GENERAL") ? 1 : 0;   // A/B switch: the general chase body in every stage
     hipLaunchKernelGGL(zmsqr_kernel, dim3((unsigned)nmat), dim3(kZL), dyn, stream, static_cast<double*>(workspace), n, w,
-                       info, prof);
+                       info, prof, general_only);
     EGS_LAUNCH_CHECK();
     return 0;
 }
