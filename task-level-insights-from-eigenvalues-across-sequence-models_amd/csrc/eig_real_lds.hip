@@ -969,6 +969,121 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
         int l = 0;
         bool converged = false;
         for (int its = 0; its <= itmax; ++its) {
+            double rt1r, rt1i, rt2r, rt2i;
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+            int m;
+            bool done = false;
+            if constexpr (V::kFast) {
+                // n = 64: everything the deflation scan, the shifts and the start search read lies on three diagonals.
+                // Lane k fetches its neighbourhood of them in ONE batch (clamped, always-valid addresses) together with
+                // the trailing 2 x 2 block, so the preamble of a sweep is one LDS round trip instead of one per
+                // section and per nested condition (it was 3.1 k cycles per sweep, 13 % of the QR stage).
+                const int k = lane, km = (k > 0) ? k - 1 : 0, kp = (k < 63) ? k + 1 : 63, kp2 = (k < 62) ? k + 2 : 63;
+                const int i1 = (i > 0) ? i - 1 : 0;
+                const double d0 = H.at(k, k), dm = H.at(km, km), dp = H.at(kp, kp);
+                const double s0 = H.at(k, km), s1 = H.at(kp, k), s2 = H.at(kp2, kp);
+                const double u0 = H.at(km, k), u1 = H.at(k, kp);
+                double h11 = H.at(i1, i1), h21 = H.at(i, i1), h12 = H.at(i1, i), h22 = H.at(i, i);
+                // ---- single small subdiagonal element: lane k tests H(k,k-1), l < k <= i (branch-free) ----
+                const double hkk1 = fabs(s0);
+                double tst = fabs(dm) + fabs(d0);
+                if (__ballot(tst == 0.0 && lane > l && lane <= i) != 0ULL) {     // rare: both diagonal entries vanish
+                    const double below = (k + 1 <= n - 1) ? fabs(s1) : 0.0;
+                    const double left = (k - 2 >= 0) ? fabs(H.at(km, (k >= 2) ? k - 2 : 0)) : 0.0;
+                    tst = (tst == 0.0) ? left + below : tst;
+                }
+                const double hk1k = fabs(u0);
+                const double ab = fmax(hkk1, hk1k), ba = fmin(hkk1, hk1k);
+                const double df = fabs(dm - d0);
+                const double aa = fmax(fabs(d0), df), bb = fmin(fabs(d0), df);
+                const double rs0 = fast_rcp(aa + ab);
+                const bool crit = ba * (ab * rs0) <= fmax(smlnum, ulp * (bb * (aa * rs0)));
+                const bool small = lane > l && lane <= i && (hkk1 <= smlnum || (hkk1 <= ulp * tst && crit));
+                const unsigned long long smask = __ballot(small);
+                l = smask ? (63 - __builtin_clzll(smask)) : l;
+                l = uniform(l);
+                if (l > 0 && lane == 0) H.at(l, l - 1) = 0.0;
+                if (l >= i - 1) {
+                    done = true;
+                } else {
+                    wave_lds_sync();
+                    ++kdefl;
+                    // ---- shifts (uniform) ----
+                    if (kdefl % kexsh == 0) {
+                        if (kdefl % (2 * kexsh) == 0) {
+                            const double s = fabs(H.at(i, i - 1)) + fabs(H.at(i - 1, i - 2));
+                            h11 = 0.75 * s + H.at(i, i);
+                            h12 = -0.4375 * s;
+                            h21 = s;
+                            h22 = h11;
+                        } else {
+                            const double s = fabs(H.at(l + 1, l)) + fabs(H.at(l + 2, l + 1));
+                            h11 = 0.75 * s + H.at(l, l);
+                            h12 = -0.4375 * s;
+                            h21 = s;
+                            h22 = h11;
+                        }
+                    }
+                    {
+                        const double s = fabs(h11) + fabs(h12) + fabs(h21) + fabs(h22);
+                        if (s == 0.0) {
+                            rt1r = rt1i = rt2r = rt2i = 0.0;
+                        } else {
+                            const double rs = fast_rcp(s);
+                            h11 *= rs;
+                            h21 *= rs;
+                            h12 *= rs;
+                            h22 *= rs;
+                            const double tr = (h11 + h22) * 0.5;
+                            const double det = (h11 - tr) * (h22 - tr) - h12 * h21;
+                            const double ad = fmax(fabs(det), 1e-300);
+                            const double rtdisc = ad * fast_rsqrt(ad);            // sqrt |det| (a shift: a few ulps are irrelevant)
+                            if (det >= 0.0) {
+                                rt1r = tr * s;
+                                rt2r = rt1r;
+                                rt1i = rtdisc * s;
+                                rt2i = -rt1i;
+                            } else {
+                                rt1r = tr + rtdisc;
+                                rt2r = tr - rtdisc;
+                                if (fabs(rt1r - h22) <= fabs(rt2r - h22)) {
+                                    rt1r = rt1r * s;
+                                    rt2r = rt1r;
+                                } else {
+                                    rt2r = rt2r * s;
+                                    rt1r = rt2r;
+                                }
+                                rt1i = 0.0;
+                                rt2i = 0.0;
+                            }
+                        }
+                    }
+                    // ---- two consecutive small subdiagonals: lane mm evaluates the start vector at row mm ----
+                    // (the scan may just have zeroed H(l, l-1): s0 of lane l is stale, and unused -- row l always starts)
+                    bool start_ok = false;
+                    {
+                        const double hmm = d0, hm1m = s1, hm1m1 = dp;
+                        double s = fabs(hmm - rt2r) + fabs(rt2i) + fabs(hm1m);
+                        double rs = fast_rcp(s);
+                        const double h21s = hm1m * rs;
+                        v0 = h21s * u1 + (hmm - rt1r) * ((hmm - rt2r) * rs) - rt1i * (rt2i * rs);
+                        v1 = h21s * (hmm + hm1m1 - rt1r - rt2r);
+                        v2 = h21s * s2;
+                        s = fabs(v0) + fabs(v1) + fabs(v2);
+                        rs = fast_rcp(s);
+                        v0 *= rs;
+                        v1 *= rs;
+                        v2 *= rs;
+                        const bool crit2 = fabs(s0) * (fabs(v1) + fabs(v2)) <= ulp * fabs(v0) * (fabs(dm) + fabs(hmm) + fabs(hm1m1));
+                        start_ok = lane >= l && lane <= i - 2 && (lane == l || crit2);
+                    }
+                    const unsigned long long mmask = __ballot(start_ok);  // bit l is always set
+                    m = uniform(63 - __builtin_clzll(mmask));
+                    v0 = bcast_lane(v0, m);
+                    v1 = bcast_lane(v1, m);
+                    v2 = bcast_lane(v2, m);
+                }
+            } else {
             // ---- look for a single small subdiagonal element: lane k tests H(k,k-1), l < k <= i ----
             bool small = false;
             if (lane > l && lane <= i) {
@@ -1000,10 +1115,8 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
             l = smask ? (63 - __builtin_clzll(smask)) : l;
             l = uniform(l);
             if (l > 0 && lane == 0) H.at(l, l - 1) = 0.0;
-            if (l >= i - 1) {
-                converged = true;
-                break;
-            }
+            if (l >= i - 1) done = true;
+            if (!done) {
             wave_lds_sync();
             ++kdefl;
 
@@ -1027,7 +1140,6 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
                 h12 = H.at(i - 1, i);
                 h22 = H.at(i, i);
             }
-            double rt1r, rt1i, rt2r, rt2i;
             {
                 const double s = fabs(h11) + fabs(h12) + fabs(h21) + fabs(h22);
                 if (s == 0.0) {
@@ -1063,7 +1175,6 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
             }
 
             // ---- two consecutive small subdiagonals: lane m evaluates the start vector at row m ----
-            double v0 = 0.0, v1 = 0.0, v2 = 0.0;
             bool start_ok = false;
             if (lane >= l && lane <= i - 2) {
                 const int mm = lane;
@@ -1090,10 +1201,16 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
                 }
             }
             const unsigned long long mmask = __ballot(start_ok);      // bit l is always set
-            const int m = uniform(63 - __builtin_clzll(mmask));
+            m = uniform(63 - __builtin_clzll(mmask));
             v0 = bcast_lane(v0, m);
             v1 = bcast_lane(v1, m);
             v2 = bcast_lane(v2, m);
+            }   // !done
+            }   // generic layouts
+            if (done) {
+                converged = true;
+                break;
+            }
 
             // ---- double-shift QR sweep: chase the bulge(s) from row m to row i (m <= i-2) ----
 #ifndef EGS_QR_SINGLE_BULGE
