@@ -503,7 +503,10 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
 constexpr int QW = 64;                  // window order
 constexpr int QLD = 65;                 // leading dimension of the LDS windows (odd: rows and columns conflict-free)
 constexpr int QM = 16;                  // bulges per chain (= wavefronts)
-constexpr int QNS = 8;                  // distinct shifts per sweep (each used twice)
+#ifndef EGS_ZQNS
+#define EGS_ZQNS 8
+#endif
+constexpr int QNS = EGS_ZQNS;           // distinct shifts per sweep (QM / QNS bulges share one)
 constexpr int QNBS = QW - 2 * QM - 1;   // time steps per window
 constexpr int QSMALL = 16;              // deflated blocks up to this order are finished by one wavefront
 constexpr int QSLD = 17;
@@ -1069,7 +1072,7 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
                 __syncthreads();
             }
         }
-        if (tid < QM) shifts[tid] = sw[tid >> 1];
+        if (tid < QM) shifts[tid] = sw[tid * QNS / QM];
         __syncthreads();
         ZSTAMP(pacc1)
         ++nsweep;
