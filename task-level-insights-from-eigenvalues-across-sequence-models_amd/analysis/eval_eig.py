@@ -569,9 +569,15 @@ def eval_eig(args, conf_args, wandb_config, data_config, loader, path_file, perf
         raise RuntimeError("{0} is not a valid model option".format(layer_type))
 
     if rank == 0:
+        shard = None
+        if hist_only and layer_type in ["mamba", "transformer"]:
+            # `exchange: histogram`: eig / eig_init hold only THIS rank's batch rows while the percentages cover the whole
+            # batch.  The arrays are saved under names that say so and the shard is recorded in used_config.yaml.
+            shard = {"exchange": "histogram", "world_size": int(_world), "rank": 0,
+                     "batch_rows": [int(rng_t[0]), int(rng_t[1])], "batch_size": int(rng_t[2])}
         _save_artifacts(args, conf_args, wandb_config, data_config, model_config, train_config, perf,
                         [eig, eig_init, percentage, percentage_init, percentage_phase, percentage_phase_init,
-                         percentage_mean, percentage_init_mean, percentage_std, percentage_init_std])
+                         percentage_mean, percentage_init_mean, percentage_std, percentage_init_std], shard)
     return eig, eig_init, percentage, percentage_init, percentage_phase, percentage_phase_init
 
 
@@ -583,8 +589,17 @@ _ARTIFACT_NAMES = ["eigen_values_", "eigen_values_init_", "percentage_", "percen
                    "percentage_init_std_"]
 
 
-def _save_artifacts(args, conf_args, wandb_config, data_config, model_config, train_config, perf, arrays):
-    """eval_eig.py:750-851: 10 .npy + used_config.yaml (+ percentage_file.txt), to a W&B artifact or a local directory."""
+def _save_artifacts(args, conf_args, wandb_config, data_config, model_config, train_config, perf, arrays, shard=None):
+    """eval_eig.py:750-851: 10 .npy + used_config.yaml (+ percentage_file.txt), to a W&B artifact or a local directory.
+    shard (histogram exchange only): the two spectra arrays are one rank's rows -- they get a `_rank0_rows<lo>-<hi>`
+    suffix instead of the reference's names, and the shard description is written into used_config.yaml."""
+    files, members = list(_ARRAY_FILES), list(_ARTIFACT_NAMES)
+    if shard is not None:
+        tag = "_rank{0}_rows{1}-{2}".format(shard["rank"], shard["batch_rows"][0], shard["batch_rows"][1])
+        files[0], files[1] = files[0] + tag, files[1] + tag
+        members[0], members[1] = members[0] + tag[1:] + "_", members[1] + tag[1:] + "_"
+        args = dict(args)
+        args["eigspec_sharding"] = shard
     report = os.path.abspath(os.getcwd()) + "/percentage_file.txt"
     dim_conv = model_config["dim_conv"] if "dim_conv" in model_config else 0
     if wandb_config is not None:
@@ -598,7 +613,7 @@ def _save_artifacts(args, conf_args, wandb_config, data_config, model_config, tr
                    name="upload" + name, job_type="add-dataset")
         artifact = wandb.Artifact(name="eigen_values_" + stem, type="dataset")
         with tempfile.TemporaryDirectory() as tmpdir:
-            for fname, arr, member in zip(_ARRAY_FILES, arrays, _ARTIFACT_NAMES):
+            for fname, arr, member in zip(files, arrays, members):
                 fpath = os.path.join(tmpdir, fname + ".npy")
                 np.save(fpath, arr)
                 artifact.add_file(local_path=fpath, name=member + name)
@@ -628,7 +643,7 @@ def _save_artifacts(args, conf_args, wandb_config, data_config, model_config, tr
         print(f"Permission denied: Unable to create '{directory}'.")
     except Exception as e:
         print(f"An error occurred: {e}")
-    for fname, arr in zip(_ARRAY_FILES, arrays):
+    for fname, arr in zip(files, arrays):
         np.save(os.path.join(directory, fname + ".npy"), arr)
     with open(os.path.join(directory, "used_config.yaml"), "w") as fh:
         yaml.dump(args, fh, default_flow_style=False, sort_keys=False)

@@ -79,3 +79,14 @@ def test_histogram_only_exchange(tmp_path):
         np.testing.assert_allclose(ranks[r]["eig_init"], single["eig_init"][lo:lo + nloc], rtol=1e-12)
         lo += nloc
     assert lo == single["eig"].shape[0]
+    # the saved spectra are rank 0's rows only: their file names and used_config.yaml say so (the percentages are complete)
+    art = [e.path for e in os.scandir(tmp_path / "w2h_rank0") if e.is_dir()]
+    assert len(art) == 1
+    names = sorted(os.listdir(art[0]))
+    nloc0 = ranks[0]["eig"].shape[0]
+    assert "eig_rank0_rows0-%d.npy" % nloc0 in names and "eig_init_rank0_rows0-%d.npy" % nloc0 in names
+    assert "eig.npy" not in names and "percentage.npy" in names
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(art[0], "used_config.yaml")))
+    assert cfg["eigspec_sharding"] == {"exchange": "histogram", "world_size": 2, "rank": 0, "batch_rows": [0, nloc0],
+                                       "batch_size": single["eig"].shape[0]}
