@@ -143,6 +143,16 @@ def test_all_gather_slabs_world2_gloo(tmp_path, n_total):
     assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]
 
 
+@pytest.mark.parametrize("world,n_total", [(4, 10), (3, 2)])
+def test_all_gather_slabs_more_ranks_gloo(tmp_path, world, n_total):
+    """Rehearsal of the 4- and 8-GPU layouts on the CPU: ragged last slab (10 units over 4 ranks: 3, 3, 3, 1) and ranks
+    that own nothing (2 units over 3 ranks)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gather_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(world)] == ["ok"] * world
+
+
 # ---- report writers / readers ------------------------------------------------------------------------------------
 def test_report_writers_match_reference_text(pkg, golden, tmp_path, monkeypatch):
     g = golden("thresholds")
