@@ -587,14 +587,29 @@ __device__ __forceinline__ long long qr_now() { return (long long)__builtin_read
 #endif
 constexpr int kNever = 1 << 20;               // validity constant of a lane that must not store
 
-// Reflector of the bulge column (a0; a1, a2) without beta.  nrm carries +1e-300 so that an all-zero column gives
-// t ~ 1e-150, u = 0 (the identity) and the reciprocal below needs no guard; a zero tail gives t1 = 2, u = 0.
+// Reflector of the bulge column (a0; a1, a2) without beta.
+// The n = 64 drivers scale every matrix by a power of two to max |entry| in [1, 2) first (hess_reg.h), so a bulge column
+// with |a|^2 < 2^-800 is negligible absolutely (|a| < 4e-121) -- and it MUST be caught: below ~1e-154 the squares
+// underflow, the norm comes out too small (zero) while the components are not, and with an exactly zero a0 (skew-symmetric
+// input has them) u = a / (|a0| + norm) explodes: the round-3 form of this routine produced eigenvalues of 1e+125 for 1.4 %
+// of random skew-symmetric matrices, whose zero diagonal keeps LAPACK's deflation test waiting until the sub-diagonal
+// itself underflows.  Such a column gets the reflection diag(-1, 1, 1) (a = (1, 0, 0): orthogonal, and its entries stay
+// where they are, below every threshold); the test is one compare and a branch that is never taken otherwise, in place
+// of the clamp the reciprocal square root needed anyway.
+constexpr double kTinyCol = 1.4996968138956309e-241;   // 2^-800
+
 __device__ __forceinline__ void larfg3_coeffs(double a0, double a1, double a2, double& t1, double& t2, double& t3,
                                               double& u1, double& u2) {
-    const double tiny = 1e-300;
-    const double nrm2 = fma(a0, a0, fma(a2, a2, a1 * a1));
-    const double rn = fast_rsqrt(fmax(nrm2, tiny));
-    const double apn = fabs(a0) + fma(nrm2, rn, tiny);             // |a0 - beta|
+    double nrm2 = fma(a0, a0, fma(a2, a2, a1 * a1));
+    if (__builtin_expect(__ballot(nrm2 < kTinyCol) != 0ULL, 0)) {  // rare: some group's bulge column is negligible
+        const bool z = nrm2 < kTinyCol;
+        a0 = z ? 1.0 : a0;
+        a1 = z ? 0.0 : a1;
+        a2 = z ? 0.0 : a2;
+        nrm2 = z ? 1.0 : nrm2;
+    }
+    const double rn = fast_rsqrt(nrm2);
+    const double apn = fabs(a0) + nrm2 * rn;                       // |a0 - beta|
     const double scal = copysign(fast_rcp(apn), a0);               // 1 / (a0 - beta)
     t1 = apn * rn;                                                 // (beta - a0) / beta
     u1 = a1 * scal;

@@ -277,12 +277,13 @@ __device__ __forceinline__ int hess_reg_reduce(double (&A)[16][4], const RegLane
             finite = finite && (fabs(A[R][C]) <= 1.7976931348623157e308);   // false for NaN and Inf
         }
     int e = 0;
-    // xGEEV-style scaling (see hess_real_kernel): matrices whose largest entry is outside [1e-140, 1e140].  Applied
-    // without a branch (factor 1 in the common case): a conditional update of all 64 registers costs spills.
+    // Scaling by a power of two to max |entry| in [1, 2) (exact; the QR stage multiplies the eigenvalues back).  xGEEV
+    // only does this outside [1e-140, 1e140]; here every matrix is normalised so that the QR sweep can call a bulge
+    // column negligible by an ABSOLUTE threshold (larfg3_coeffs in eig_real_lds.hip) before its squares underflow.
     if (scaling) {
         amax = wave_max(amax);
         if (__ballot(!finite) != 0ULL) e = kRegNonFinite;
-        else if (amax > 0.0 && (amax < 1e-140 || amax > 1e140)) e = ilogb(amax);
+        else if (amax > 0.0) e = ilogb(amax);
     }
     {
         const double sc = (e != 0 && e != kRegNonFinite) ? scalbn(1.0, -e) : 1.0;

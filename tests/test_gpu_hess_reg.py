@@ -227,3 +227,31 @@ def test_two_bulge_sweep_is_backward_stable_on_hard_structures(gpu_ops):
         smin = np.linalg.svd(m, compute_uv=False)[:, -1]
         worst = max(worst, float(np.max(smin) / nrm[k]))
     assert worst < 1e-13 * n, worst
+
+
+def test_skew_symmetric_and_zero_diagonal_matrices(gpu_ops):
+    """Regression (round 3): a skew-symmetric matrix reduces to a tridiagonal form with an exactly / nearly zero diagonal,
+    for which LAPACK's deflation test waits until the sub-diagonal itself underflows; the bulge column then passes through
+    magnitudes whose squares underflow.  A reflector built from such a column produced eigenvalues of 1e+125 for 1.4 %
+    of random skew-symmetric 64 x 64 matrices (no failure flag).  2048 of them, plus zero-diagonal non-normal ones and
+    globally tiny / huge scalings of both."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    n, nmat = 64, 2048
+    s = torch.randn((nmat, n, n), generator=g, device="cuda", dtype=torch.float64) / 16
+    skew = s - s.transpose(1, 2)
+    zd = s.clone()
+    zd.diagonal(dim1=1, dim2=2).zero_()
+    for name, a in (("skew", skew), ("zero-diagonal", zd), ("skew * 1e-150", skew * 1e-150), ("skew * 1e150", skew * 1e150)):
+        w, info = gpu_ops.eig_general_batched(a)
+        assert int(info.abs().sum().item()) == 0, name
+        nrm = torch.linalg.matrix_norm(a)
+        assert bool(torch.isfinite(torch.view_as_real(w)).all()), name
+        assert float((w.abs().max(dim=1).values / nrm).max().item()) < 1.0 + 1e-9, name        # |lambda| <= ||A||_F
+        tr2 = (a * a.transpose(1, 2)).sum(dim=(1, 2))                                          # tr(A^2) = sum lambda^2
+        assert float((((w * w).sum(dim=1) - tr2).abs() / nrm ** 2).max().item()) < 1e-12, name
+        if name.startswith("skew"):
+            assert float((w.real.abs().max(dim=1).values / nrm).max().item()) < 1e-13, name   # purely imaginary spectrum
+    ref = np.linalg.eigvals(skew[:64].cpu().numpy())
+    w, _ = gpu_ops.eig_general_batched(skew[:64].contiguous())
+    assert O.max_abs_dlambda(w.cpu().numpy(), ref) < 1e-12

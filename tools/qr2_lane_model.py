@@ -16,11 +16,13 @@ PAD = 80
 
 
 def coeffs(a0, a1, a2):
-    tiny = 1e-300
+    """larfg3_coeffs of the kernel: a column with |a|^2 < 2^-800 (the drivers scale the matrix to max |entry| in [1, 2))
+    gets the reflection diag(-1, 1, 1) instead of a reflector built from underflowed squares."""
     nrm2 = a0 * a0 + (a2 * a2 + a1 * a1)
-    rn = 1.0 / math.sqrt(max(nrm2, tiny))
-    nrm = nrm2 * rn + tiny
-    apn = abs(a0) + nrm
+    if nrm2 < 2.0 ** -800:
+        a0, a1, a2, nrm2 = 1.0, 0.0, 0.0, 1.0
+    rn = 1.0 / math.sqrt(nrm2)
+    apn = abs(a0) + nrm2 * rn
     scal = math.copysign(1.0 / apn, a0)
     t1 = apn * rn
     u1, u2 = a1 * scal, a2 * scal

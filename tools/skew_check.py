@@ -1,0 +1,21 @@
+import importlib, os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+ops = importlib.import_module("task-level-insights-from-eigenvalues-across-sequence-models_amd").ops
+n = 64; nper = int(os.environ.get("NPER", 2048))
+rng = np.random.default_rng(int(os.environ.get("SEED", 7)))
+rng.standard_normal((nper, n, n)); rng.standard_normal((nper, n, n)); rng.uniform(-6, 0, (nper, n, 1))   # same stream position as stress_c2
+s = rng.standard_normal((nper, n, n))
+m = (s - s.transpose(0, 2, 1)) / 16
+w, info = ops.eig_general_batched(torch.from_numpy(np.ascontiguousarray(m)).cuda())
+w = w.cpu().numpy()
+big = np.where(~np.isfinite(w).all(axis=1) | (np.abs(w).max(axis=1) > 10))[0]
+ref = np.linalg.eigvals(m)
+err = np.abs(np.sort_complex(w) - np.sort_complex(ref)).max(axis=1)
+print(json.dumps({"lib": os.environ.get("EGS_LIB_PATH", "tree"), "bad_count": int(len(big)), "first_bad": big[:8].tolist(),
+                  "n_err_gt_1e-8": int((err > 1e-8).sum()), "info_nonzero": int((info != 0).sum().item()),
+                  "max_abs_w": float(np.nanmax(np.abs(w)))}))
+if len(big):
+    np.save(os.path.join(ROOT, "gpurun_out", "skew_bad.npy"), m[big[:4]])
