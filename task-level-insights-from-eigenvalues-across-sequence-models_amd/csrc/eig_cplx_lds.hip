@@ -58,6 +58,35 @@ __global__ __launch_bounds__(kZH) void zhess64_kernel(const double* __restrict__
         if (tid == 0) info[mat] = n;
         return;
     }
+    // xGEEV-style scaling: a matrix whose largest entry is outside [1e-100, 1e100] is scaled by a power of two (exact),
+    // the QR kernel multiplies the eigenvalues back.  Without it the squared moduli of the rotations / reflectors
+    // underflow (entries of 1e-160 gave wrong spectra without any flag) or overflow.  The exponent travels in the first
+    // slot of this matrix's eigenvalue array, which the QR kernel reads before it writes anything.
+    {
+        double amax = 0.0;
+        for (int idx = tid; idx < n * n; idx += kZH) {
+            const zq v = H[(idx / n) * ldh + (idx % n)];
+            amax = fmax(amax, fmax(fabs(v.re), fabs(v.im)));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
+        double* red = reinterpret_cast<double*>(part);
+        if (lane == 0) red[wv] = amax;
+        __syncthreads();
+        amax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        __syncthreads();
+        int e = 0;
+        if (amax > 0.0 && (amax < 1e-100 || amax > 1e100)) e = ilogb(amax);
+        if (e != 0) {
+            const double sc = scalbn(1.0, -e);
+            for (int idx = tid; idx < n * n; idx += kZH) {
+                zq& v = H[(idx / n) * ldh + (idx % n)];
+                v = {v.re * sc, v.im * sc};
+            }
+            __syncthreads();
+        }
+        if (tid == 0) w[mat * 2 * (int64_t)n] = (double)e;
+    }
     const int lc = (lane < n) ? lane : n - 1;
     const bool inr = lane < n;
     // ---- xGEBAL (permute + scale), by wave 0; same scheme as hess_real_kernel: isolated eigenvalues are moved to the
@@ -273,7 +302,7 @@ int zhess64_launch(const void* a, bool in_real, int64_t nmat, int n, int lda, in
 
 template <class V>
 __device__ __forceinline__ void zhqr_run(const V H, const double* __restrict__ src, int n, int lane,
-                                         double* __restrict__ wo, int32_t* __restrict__ info) {
+                                         double* __restrict__ wo, int32_t* __restrict__ info, const double rescale) {
     // Hessenberg part plus the one extra sub-diagonal a single-shift bulge touches; 8 rows of 16-byte global loads in
     // flight at a time from always-valid addresses (clamped lane), zeroed / dropped by value afterwards
     const int lcl = (lane < n) ? lane : n - 1;
@@ -292,7 +321,7 @@ __device__ __forceinline__ void zhqr_run(const V H, const double* __restrict__ s
         if (lane < n && i <= lane + 2) H.at(i, lane) = (i <= lane + 1) ? t : zq{0.0, 0.0};
     }
     wave_lds_sync();
-    zhqr_wave(H, n, lane, wo, info);
+    zhqr_wave(H, n, lane, wo, info, rescale);
 }
 
 // info[mat] may arrive pre-set to n by the Hessenberg stage (non-finite input): such matrices are skipped.
@@ -309,12 +338,15 @@ __global__ __launch_bounds__(256) void zhqr_wave_kernel(const double* __restrict
     zq* base = reinterpret_cast<zq*>(smem) + (size_t)(wave >> 1) * ((size_t)n * ldp);
     const double* src = hin + mat * 2 * (int64_t)n * n;
     double* wo = w + mat * 2 * (int64_t)n;
+    // the Hessenberg stage left the power-of-two exponent it scaled this matrix by in the first eigenvalue slot
+    const int sexp = __builtin_amdgcn_readfirstlane((int)wo[0]);
+    const double rescale = (sexp != 0) ? scalbn(1.0, sexp) : 1.0;
     if (n == 64) {
-        if ((wave & 1) == 0) zhqr_run(ZViewT<69, false>{base + 5, ldp}, src, n, lane, wo, info + mat);
-        else zhqr_run(ZViewT<69, true>{base, ldp}, src, n, lane, wo, info + mat);
+        if ((wave & 1) == 0) zhqr_run(ZViewT<69, false>{base + 5, ldp}, src, n, lane, wo, info + mat, rescale);
+        else zhqr_run(ZViewT<69, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
     } else {
-        if ((wave & 1) == 0) zhqr_run(ZViewT<0, false>{base + 5, ldp}, src, n, lane, wo, info + mat);
-        else zhqr_run(ZViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat);
+        if ((wave & 1) == 0) zhqr_run(ZViewT<0, false>{base + 5, ldp}, src, n, lane, wo, info + mat, rescale);
+        else zhqr_run(ZViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
     }
 }
 

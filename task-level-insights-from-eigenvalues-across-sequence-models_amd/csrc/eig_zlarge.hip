@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
     {
         const double* src = a + mat * stride * (in_real ? 1 : 2);
         bool bad = false;
+        double amax = 0.0;
         for (int idx = tid; idx < n * n; idx += kZL) {
             const int j = idx / n, i = idx - j * n;          // M(i,j) = A(j,i) = src[j*lda + i]
             zq v;
@@ -80,8 +81,12 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
             else v = {src[2 * ((int64_t)j * lda + i)], src[2 * ((int64_t)j * lda + i) + 1]};
             M[idx] = v;
             if (!(fabs(v.re) <= 1.7976931348623157e308) || !(fabs(v.im) <= 1.7976931348623157e308)) bad = true;
+            amax = fmax(amax, fmax(fabs(v.re), fabs(v.im)));
         }
         if (bad) s_idx = 1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
+        if (lane == 0) red[wv] = amax;
     }
     __syncthreads();
     if (s_idx != 0) {                    // NaN / Inf input: an error like numpy.linalg.eigvals, not a spectrum
@@ -92,6 +97,24 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
         return;
     }
     if (tid == 0) info_out[mat] = 0;
+    // xGEEV-style scaling: largest entry outside [1e-100, 1e100] -> scale by a power of two (exact); the QR kernel
+    // multiplies the eigenvalues back (exponent in the first eigenvalue slot, read before anything is written there).
+    // Without it squared moduli underflow / overflow: entries of 1e-160 made every matrix fail to converge.
+    {
+        double amax = 0.0;
+        for (int x = 0; x < kZLW; ++x) amax = fmax(amax, red[x]);
+        int e = 0;
+        if (amax > 0.0 && (amax < 1e-100 || amax > 1e100)) e = ilogb(amax);
+        if (e != 0) {
+            const double sc = scalbn(1.0, -e);
+            for (int idx = tid; idx < n * n; idx += kZL) {
+                const zq v = M[idx];
+                M[idx] = {v.re * sc, v.im * sc};
+            }
+        }
+        if (tid == 0) w[mat * 2 * (int64_t)n] = (double)e;
+        __syncthreads();
+    }
 
     // ---- xGEBAL: permutation to isolate eigenvalues + power-of-two equilibration (what xGEEV does first) ----
     if (balance) {
@@ -969,6 +992,9 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
     zq* mbx = prm + 6 * QM;                      // [2][QM][3] look-ahead mailbox
     zq* H = reinterpret_cast<zq*>(work) + mat * (int64_t)n * n;
     zq* wout = reinterpret_cast<zq*>(w) + mat * (int64_t)n;
+    const int sexp = (int)w[mat * 2 * (int64_t)n];                   // scaling exponent left by the Hessenberg stage
+    const double rescale = (sexp != 0) ? scalbn(1.0, sexp) : 1.0;
+    __syncthreads();                                                  // everybody has read it before slot 0 can be written
 #define HG(r, c) H[(int64_t)(c) * n + (r)]
     const double ulp = 2.220446049250313e-16;
     const double safmin = 2.2250738585072014e-308;
@@ -1018,7 +1044,7 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
         if (l > 0 && tid == 0) HG(l, l - 1) = {0.0, 0.0};
         __syncthreads();
         if (l == i) {
-            if (tid == 0) wout[i] = HG(i, i);
+            if (tid == 0) wout[i] = qscale(HG(i, i), rescale);
             --i;
             stall = 0;
             continue;
@@ -1039,7 +1065,7 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
                 info = l + s_info;
                 break;
             }
-            if (tid < na) wout[l + tid] = sw[tid];
+            if (tid < na) wout[l + tid] = qscale(sw[tid], rescale);
             i = l - 1;
             stall = 0;
             __syncthreads();

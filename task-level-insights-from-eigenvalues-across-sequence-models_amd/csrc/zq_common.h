@@ -104,7 +104,7 @@ __device__ __forceinline__ zq qdiv_fast(zq a, zq b) {
 // seed-based arithmetic in the Wilkinson shift.  SHIFTS = false is the xLAHQR iteration that produces final spectra.
 template <class V, bool SHIFTS = false>
 __device__ void zhqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
-                          int32_t* __restrict__ info_out) {
+                          int32_t* __restrict__ info_out, const double rescale = 1.0) {
     const double ulp = SHIFTS ? 1e-11 : 2.220446049250313e-16;
     const double safmin = 2.2250738585072014e-308;
     const double smlnum = safmin * ((double)n / ulp);
@@ -262,8 +262,8 @@ __device__ void zhqr_wave(const V H, const int n, const int lane, double* __rest
         {
             const zq e = H.at(i, i);
             if (lane == 0) {
-                w_out[2 * i] = e.re;
-                w_out[2 * i + 1] = e.im;
+                w_out[2 * i] = e.re * rescale;
+                w_out[2 * i + 1] = e.im * rescale;
             }
         }
         kdefl = 0;

@@ -270,3 +270,25 @@ def test_c5_batch_properties(gpu_ops):
     nrm = torch.linalg.matrix_norm(ab, ord="fro")
     assert float(((w.sum(dim=1) - tr).abs() / nrm).max().item()) < 1e-11 * n
     assert float((((w * w).sum(dim=1) - tr2).abs() / nrm ** 2).max().item()) < 1e-11 * n
+
+
+@pytest.mark.parametrize("n,cplx", [(24, True), (64, True), (96, False), (128, True)])
+@pytest.mark.parametrize("k", [-530, 530])
+def test_extreme_global_scale_on_the_complex_and_level3_paths(gpu_ops, n, cplx, k):
+    """Regression (round 3): the complex n <= 64 kernels and the level-3 path had no xGEEV-style scaling -- entries of
+    1e-160 gave wrong spectra without a flag (n <= 64) or 'not converged' for every matrix (n > 64).  A * 2^k has the
+    spectrum 2^k * spec(A) exactly; skew-Hermitian input is the hard case (zero diagonal: late deflation)."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1000 + n)
+    x = torch.randn((6, n, n), generator=g, device="cuda", dtype=torch.float64)
+    if cplx:
+        x = torch.complex(x, torch.randn((6, n, n), generator=g, device="cuda", dtype=torch.float64))
+    a = (x - x.transpose(1, 2).conj()) / (2 * np.sqrt(n))
+    a[3:] = x[3:] / (2 * np.sqrt(n))                                   # three skew(-Hermitian), three dense
+    w0, info0 = gpu_ops.eig_general_batched(a.contiguous())
+    w1, info1 = gpu_ops.eig_general_batched((a * 2.0 ** k).contiguous())
+    assert int(info0.abs().sum().item()) == 0 and int(info1.abs().sum().item()) == 0
+    got = (w1 * 2.0 ** (-k)).cpu().numpy()
+    ref = np.linalg.eigvals(a.cpu().numpy())
+    assert O.max_abs_dlambda(got, ref) < 1e-11
+    assert O.max_abs_dlambda(got, w0.cpu().numpy()) < 1e-11
