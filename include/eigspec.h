@@ -102,7 +102,11 @@ int egs_eig_general_batched(const void* a, int dtype, int64_t nmat, int n, int l
 /* The two stages of the level-3 path (n > 64 .. 1024), exposed separately like LAPACK's xGEHRD / xHSEQR.
  *   egs_hessenberg_general_batched : a (dtype as above, row-major, not modified) -> h, complex128[nmat, n, n]: the
  *       upper-Hessenberg reduction of the TRANSPOSE of each (balanced) matrix, stored column-major -- i.e. read as a
- *       row-major [n, n] array, h is LOWER Hessenberg and has the eigenvalues of a.  info[m] = n flags NaN / Inf input.
+ *       row-major [n, n] array, h is LOWER Hessenberg.  Each matrix is first scaled by a power of two, 2^-e, to a largest
+ *       entry in [1, 2) (exact; what xGEEV does outside [sqrt(safmin), sqrt(safmax)], here always, so that the QR stage
+ *       can use absolute negligibility thresholds): h has the eigenvalues of 2^-e a, and e travels as a double in the first
+ *       slot of w (w[m][0].re), where egs_hseqr_general_batched picks it up and multiplies the eigenvalues back -- pass
+ *       the same w to both calls.  info[m] = n flags NaN / Inf input.
  *   egs_hseqr_general_batched      : h as produced above (destroyed) -> w complex128[nmat, n], info.  Diagnostics:
  *       phase_cycles = NULL, or device double[nmat, 12] receiving per matrix the shader-clock cycles spent in the
  *       deflation scans, shift generator / small blocks, window load + store, bulge chase, deferred matrix-core

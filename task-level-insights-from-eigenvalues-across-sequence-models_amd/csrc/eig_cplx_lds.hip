@@ -188,8 +188,12 @@ __global__ __launch_bounds__(kZH) void zhess64_kernel(const double* __restrict__
         const zq xi = (lane > k && inr) ? ZH(lane, k) : zq{0.0, 0.0};
         const zq alpha = qbcast(xi, k + 1);
         const double xnorm2 = wave_sum((lane > k + 1) ? fma(xi.re, xi.re, xi.im * xi.im) : 0.0);
-        const bool act = !(xnorm2 == 0.0 && alpha.im == 0.0);          // block-uniform
-        const double nrm = sqrt(fma(alpha.re, alpha.re, alpha.im * alpha.im) + xnorm2);
+        // block-uniform.  A column whose squared norm is below 1e-290 is left alone: its squares underflow, the norm would
+        // come out as zero and tau as NaN (c (1 + i/2) ones(64, 64) did that); the matrix is scaled so that its largest
+        // entry is >= 1e-100, i.e. such a column is below 1e-45 of it.  The QR stage drops what stays under the sub-diagonal.
+        const double tot = fma(alpha.re, alpha.re, alpha.im * alpha.im) + xnorm2;
+        const bool act = !(xnorm2 == 0.0 && alpha.im == 0.0) && tot >= 1e-290;
+        const double nrm = sqrt(tot);
         const double beta = act ? -copysign(nrm, alpha.re) : alpha.re;
         const zq tau = act ? zq{(beta - alpha.re) / beta, -alpha.im / beta} : zq{0.0, 0.0};
         const zq sc = act ? qdiv({1.0, 0.0}, {alpha.re - beta, alpha.im}) : zq{0.0, 0.0};

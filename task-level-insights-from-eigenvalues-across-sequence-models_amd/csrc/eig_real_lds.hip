@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
         }
     }
     wave_lds_sync();
-    // xGEEV-style scaling: matrices whose largest entry is outside [1e-140, 1e140] are scaled by a power of two so
+    // xGEEV-style scaling: matrices whose largest entry is outside [1e-100, 1e100] are scaled by a power of two so
     // that the unscaled reflector arithmetic (squares of entries) cannot overflow / underflow; the QR stage multiplies
     // the eigenvalues back.  The exponent travels in the info slot between the two kernels.
     if (scale_exp != nullptr) {
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
         for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
         int e = 0;
         if (__ballot(!finite) != 0ULL) e = kNonFinite;           // NaN / Inf input: the QR stage reports failure
-        else if (amax > 0.0 && (amax < 1e-140 || amax > 1e140)) e = ilogb(amax);
+        else if (amax > 0.0 && (amax < 1e-100 || amax > 1e100)) e = ilogb(amax);
         if (e != 0 && e != kNonFinite) {
             const double sc = scalbn(1.0, -e);
             for (int i = 0; i < n; ++i)
@@ -279,6 +279,9 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
         const double alpha = bcast_lane(xi, k + 1);
         const double xnorm2 = wave_sum((lane > k + 1) ? xi * xi : 0.0);
         if (xnorm2 == 0.0) continue;               // wave-uniform: nothing to annihilate
+        // squares in or below the denormal range: the norm would be inaccurate and the reflector not orthogonal; with the
+        // scaling above such a column is below 1e-45 of the matrix and is left to the QR stage, which drops it
+        if (alpha * alpha + xnorm2 < 1e-290) continue;
         const double nrm = sqrt(alpha * alpha + xnorm2);
         const double beta = -copysign(nrm, alpha);
         const double tau = (beta - alpha) / beta;
@@ -588,25 +591,31 @@ __device__ __forceinline__ long long qr_now() { return (long long)__builtin_read
 constexpr int kNever = 1 << 20;               // validity constant of a lane that must not store
 
 // Reflector of the bulge column (a0; a1, a2) without beta.
-// The n = 64 drivers scale every matrix by a power of two to max |entry| in [1, 2) first (hess_reg.h), so a bulge column
-// with |a|^2 < 2^-800 is negligible absolutely (|a| < 4e-121) -- and it MUST be caught: below ~1e-154 the squares
-// underflow, the norm comes out too small (zero) while the components are not, and with an exactly zero a0 (skew-symmetric
-// input has them) u = a / (|a0| + norm) explodes: the round-3 form of this routine produced eigenvalues of 1e+125 for 1.4 %
-// of random skew-symmetric matrices, whose zero diagonal keeps LAPACK's deflation test waiting until the sub-diagonal
-// itself underflows.  Such a column gets the reflection diag(-1, 1, 1) (a = (1, 0, 0): orthogonal, and its entries stay
-// where they are, below every threshold); the test is one compare and a branch that is never taken otherwise, in place
-// of the clamp the reciprocal square root needed anyway.
+// The fast path squares the components as they are.  Below |a| ~ 1e-154 the squares underflow: the norm comes out too
+// small (or zero) while the components are not, and with an exactly zero a0 (skew-symmetric input has them)
+// u = a / (|a0| + norm) explodes -- the first form of this routine returned eigenvalues of 1e+125, without a flag, for
+// 1.4 % of random skew-symmetric matrices, whose zero diagonal keeps LAPACK's deflation test waiting until the
+// sub-diagonal itself underflows; a constant matrix (Hessenberg form: a cascade down to a trailing block of 1e-190) never
+// converged.  So: a column with |a|^2 < 2^-800 takes a rare branch that rescales it by a power of two first (u and t are
+// invariant under scaling of a -- this is xLARFG's rescaling), and an exactly zero column gets the reflection
+// diag(-1, 1, 1).  The test is one compare and a never-taken branch in place of the clamp the reciprocal square root
+// needed anyway.  (The n = 64 drivers scale every matrix to max |entry| in [1, 2), hess_reg.h, and deflate sub-diagonal
+// entries below 1e-200 absolutely, so that nothing iterates on blocks near the underflow threshold itself.)
 constexpr double kTinyCol = 1.4996968138956309e-241;   // 2^-800
 
 __device__ __forceinline__ void larfg3_coeffs(double a0, double a1, double a2, double& t1, double& t2, double& t3,
                                               double& u1, double& u2) {
     double nrm2 = fma(a0, a0, fma(a2, a2, a1 * a1));
-    if (__builtin_expect(__ballot(nrm2 < kTinyCol) != 0ULL, 0)) {  // rare: some group's bulge column is negligible
+    if (__builtin_expect(__ballot(nrm2 < kTinyCol) != 0ULL, 0)) {  // rare: some group's bulge column is tiny
         const bool z = nrm2 < kTinyCol;
-        a0 = z ? 1.0 : a0;
-        a1 = z ? 0.0 : a1;
-        a2 = z ? 0.0 : a2;
-        nrm2 = z ? 1.0 : nrm2;
+        const double big = fmax(fabs(a0), fmax(fabs(a1), fabs(a2)));
+        const bool nz = big > 0.0;
+        const int e = nz ? ilogb(big) : 0;
+        const double b0 = nz ? scalbn(a0, -e) : 1.0, b1 = nz ? scalbn(a1, -e) : 0.0, b2 = nz ? scalbn(a2, -e) : 0.0;
+        a0 = z ? b0 : a0;
+        a1 = z ? b1 : a1;
+        a2 = z ? b2 : a2;
+        nrm2 = z ? fma(b0, b0, fma(b2, b2, b1 * b1)) : nrm2;
     }
     const double rn = fast_rsqrt(nrm2);
     const double apn = fabs(a0) + nrm2 * rn;                       // |a0 - beta|
@@ -971,7 +980,10 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
                          int32_t* __restrict__ info_out, const double rescale) {
     const double ulp = 2.220446049250313e-16;                      // dlamch('P')
     const double safmin = 2.2250738585072014e-308;
-    const double smlnum = safmin * ((double)n / ulp);
+    // n = 64 layouts: the matrix was scaled to max |entry| in [1, 2), so a sub-diagonal entry below 1e-200 is negligible
+    // ABSOLUTELY (xLAHQR's smlnum is 6e-291: with a zero diagonal its relative tests never fire and the iteration would
+    // chase blocks all the way down into the underflow range)
+    const double smlnum = V::kFast ? 1e-200 : safmin * ((double)n / ulp);
     const int itmax = 30 * (n > 10 ? n : 10);
     const int kexsh = 10;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);

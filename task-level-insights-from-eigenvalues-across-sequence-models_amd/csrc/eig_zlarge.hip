@@ -97,14 +97,16 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
         return;
     }
     if (tid == 0) info_out[mat] = 0;
-    // xGEEV-style scaling: largest entry outside [1e-100, 1e100] -> scale by a power of two (exact); the QR kernel
+    // xGEEV-style scaling by a power of two (exact); the QR kernel
     // multiplies the eigenvalues back (exponent in the first eigenvalue slot, read before anything is written there).
     // Without it squared moduli underflow / overflow: entries of 1e-160 made every matrix fail to converge.
     {
         double amax = 0.0;
         for (int x = 0; x < kZLW; ++x) amax = fmax(amax, red[x]);
         int e = 0;
-        if (amax > 0.0 && (amax < 1e-100 || amax > 1e100)) e = ilogb(amax);
+        // always normalised (max |entry| in [1, 2), exact): the QR stage then calls a sub-diagonal entry below 1e-200
+        // negligible absolutely instead of chasing blocks down to the underflow threshold
+        if (amax > 0.0) e = ilogb(amax);
         if (e != 0) {
             const double sc = scalbn(1.0, -e);
             for (int idx = tid; idx < n * n; idx += kZL) {
@@ -300,8 +302,12 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
             for (int x = 0; x < kZLW; ++x) xnorm2 += red[x];
             const zq alpha = s_alpha;
             // (c) reflector (block-uniform scalars)
-            const bool act = !(xnorm2 == 0.0 && alpha.im == 0.0);
-            const double nrm = sqrt(fma(alpha.re, alpha.re, alpha.im * alpha.im) + xnorm2);
+            // A column whose squared norm is below 2^-800 is left alone (tau = 0; its sub-sub-diagonal part, < 4e-121 of
+            // a matrix scaled to max |entry| in [1, 2), is dropped): further down the squares underflow, the norm comes
+            // out as zero and tau = (beta - alpha) / beta as NaN -- the trailing columns of c * ones(128, 128) did.
+            const double tot = fma(alpha.re, alpha.re, alpha.im * alpha.im) + xnorm2;
+            const bool act = !(xnorm2 == 0.0 && alpha.im == 0.0) && tot >= 1.4996968138956309e-241;
+            const double nrm = sqrt(tot);
             const double beta = act ? -copysign(nrm, alpha.re) : alpha.re;
             const zq tau = qsel(act, zq{(beta - alpha.re) / beta, -alpha.im / beta}, zq{0.0, 0.0});
             const zq sc = qsel(act, qdiv({1.0, 0.0}, {alpha.re - beta, alpha.im}), zq{0.0, 0.0});
@@ -592,11 +598,26 @@ __device__ __forceinline__ void zchase(zq* __restrict__ Wn, zq* __restrict__ Un,
 
 // Complex Givens rotation with a REAL cosine:  Q = [[c, s], [-conj(s), c]],  Q (a0; a1) = (rho; 0).
 // Applying it to a pair of complex numbers costs 12 fused multiply-adds (the 2-element Householder form: 18).
+// A pair whose squared moduli would underflow (|a|^2 < 2^-800) is rescaled by a power of two first: c and s are invariant,
+// rho scales back.  Without it such a pair got the identity and was never annihilated -- a constant matrix, whose
+// Hessenberg form cascades down to blocks of 1e-190, did not converge (round 3, tools/stress_paths.py).
 __device__ __forceinline__ void zgivens(zq a0, zq a1, double& c, zq& sn, zq& rho) {
     const double tiny = 1e-300;
-    const double n0 = fma(a0.re, a0.re, a0.im * a0.im);
-    const double n1 = fma(a1.re, a1.re, a1.im * a1.im);
-    const double nn = n0 + n1;
+    double n0 = fma(a0.re, a0.re, a0.im * a0.im);
+    double n1 = fma(a1.re, a1.re, a1.im * a1.im);
+    double nn = n0 + n1;
+    int back = 0;
+    if (nn < 1.4996968138956309e-241) {                                // rare, per lane
+        const double big = fmax(fmax(fabs(a0.re), fabs(a0.im)), fmax(fabs(a1.re), fabs(a1.im)));
+        if (big > 0.0) {
+            back = ilogb(big);
+            a0 = {scalbn(a0.re, -back), scalbn(a0.im, -back)};
+            a1 = {scalbn(a1.re, -back), scalbn(a1.im, -back)};
+            n0 = fma(a0.re, a0.re, a0.im * a0.im);
+            n1 = fma(a1.re, a1.re, a1.im * a1.im);
+            nn = n0 + n1;
+        }
+    }
     const double rn = fast_rsqrt(fmax(nn, tiny));                       // 1 / norm
     const double r0 = fast_rsqrt(fmax(n0, tiny));                       // 1 / |a0|
     const bool z0 = n0 < tiny;
@@ -605,6 +626,7 @@ __device__ __forceinline__ void zgivens(zq a0, zq a1, double& c, zq& sn, zq& rho
     c = zz ? 1.0 : (z0 ? 0.0 : n0 * r0 * rn);
     sn = qsel(zz, zq{0.0, 0.0}, qscale(qmulc(sg, a1), rn));                 // sg conj(a1) / norm
     rho = zz ? a0 : qscale(sg, nn * rn);
+    if (back != 0) rho = {scalbn(rho.re, back), scalbn(rho.im, back)};
 }
 // rows:    (x0; x1) <- Q (x0; x1)
 __device__ __forceinline__ void zrot_rows(double c, zq sn, zq x0, zq x1, zq& y0, zq& y1) {
@@ -998,7 +1020,8 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
 #define HG(r, c) H[(int64_t)(c) * n + (r)]
     const double ulp = 2.220446049250313e-16;
     const double safmin = 2.2250738585072014e-308;
-    const double smlnum = safmin * ((double)n / ulp);
+    const double smlnum = 1e-200;                // absolute: the Hessenberg stage scaled the matrix to max |entry| in [1, 2)
+    (void)safmin;
     int info = 0;
     int i = n - 1;
     int stall = 0;

@@ -171,7 +171,10 @@ __device__ __forceinline__ void hess_panel(double (&A)[16][4], const RegLane& L,
         const double xnorm2 = sum_q(sum_c((L.lane > j + 1) ? xi * xi : 0.0));
         // nothing to annihilate (wave-uniform): the step runs with tau = 0, which leaves A unchanged bit for bit -- a
         // branch around the step would make every register of A a loop-carried phi and costs more than the idle step
-        const bool live = xnorm2 != 0.0;
+        // (a column whose squared norm is below 2^-800 counts as annihilated too: the matrix is scaled to max |entry| in
+        // [1, 2), and between ~1e-162 and ~1e-150 the squares are denormal or gone while the entries are not, which
+        // would make tau and v inconsistent -- a reflector that is not orthogonal, applied to the whole matrix)
+        const bool live = xnorm2 != 0.0 && fma(alpha, alpha, xnorm2) >= 1.4996968138956309e-241;
         const double tiny = 1e-300;
         const double nrm2 = fma(alpha, alpha, xnorm2);
         const double rn = fast_rsqrt(fmax(nrm2, tiny));

@@ -49,8 +49,11 @@ def test_hessenberg_stage_matches_prototype_and_similarity(gpu_ops, n, monkeypat
     h = h.cpu().numpy()
     assert int(info.abs().sum().item()) == 0
     nb = 16 if n <= 256 else (8 if n <= 512 else 4)
+    sexp = w[:, 0].real.cpu().numpy()                 # the stage scales by 2^-e (max |entry| in [1, 2)); e in w[m, 0]
+    amax = np.maximum(np.abs(a.real), np.abs(a.imag)).reshape(2, -1).max(axis=1)
+    assert np.all(sexp == np.floor(np.log2(amax)))
     for m in range(2):
-        hm = h[m].T                                   # the kernel reduces the transpose, stored column-major
+        hm = h[m].T * 2.0 ** sexp[m]                  # the kernel reduces the transpose, stored column-major
         assert np.all(np.tril(hm, -2) == 0.0)
         np.testing.assert_allclose(np.trace(hm), np.trace(a[m]), rtol=0, atol=1e-12 * n)
         np.testing.assert_allclose(np.linalg.norm(hm), np.linalg.norm(a[m]), rtol=1e-13)
@@ -292,3 +295,21 @@ def test_extreme_global_scale_on_the_complex_and_level3_paths(gpu_ops, n, cplx, 
     ref = np.linalg.eigvals(a.cpu().numpy())
     assert O.max_abs_dlambda(got, ref) < 1e-11
     assert O.max_abs_dlambda(got, w0.cpu().numpy()) < 1e-11
+
+
+@pytest.mark.parametrize("n,cplx", [(96, False), (128, True), (40, False), (64, True)])
+def test_constant_matrices_converge_on_every_path(gpu_ops, n, cplx):
+    """Regression (round 3): c * ones(n, n) has a Hessenberg form that cascades down to blocks of 1e-190; a rotation that
+    treated a pair with underflowing squared moduli as 'nothing to rotate' never annihilated it and the level-3 path
+    reported 'not converged' for one matrix in six.  Spectrum: {n c, 0 x (n-1)}."""
+    c = torch.linspace(0.5, 2.0, 48, dtype=torch.float64, device="cuda")
+    a = torch.ones((48, n, n), dtype=torch.float64, device="cuda") * c[:, None, None]
+    if cplx:
+        a = torch.complex(a, 0.5 * a)
+    w, info = gpu_ops.eig_general_batched(a.contiguous())
+    assert int(info.abs().sum().item()) == 0
+    w = w.cpu().numpy()
+    want = n * c.cpu().numpy() * ((1 + 0.5j) if cplx else 1.0)
+    top = np.abs(w).argmax(axis=1)
+    np.testing.assert_allclose(w[np.arange(48), top], want, rtol=1e-12)
+    assert np.sort(np.abs(w), axis=1)[:, :-1].max() < 1e-11

@@ -255,3 +255,34 @@ def test_skew_symmetric_and_zero_diagonal_matrices(gpu_ops):
     ref = np.linalg.eigvals(skew[:64].cpu().numpy())
     w, _ = gpu_ops.eig_general_batched(skew[:64].contiguous())
     assert O.max_abs_dlambda(w.cpu().numpy(), ref) < 1e-12
+
+
+def test_constant_rank_one_and_nilpotent_matrices(gpu_ops):
+    """Regression (round 3): c * ones(64, 64) reduces to a Hessenberg form whose entries cascade down to a trailing block
+    of 1e-190 -- bulge columns whose squares underflow.  A reflector that ignored such columns never converged (166 of
+    256 matrices flagged); they are rescaled now, and sub-diagonal entries below 1e-200 of the normalised matrix deflate."""
+    n = 64
+    c = torch.linspace(0.5, 2.0, 256, dtype=torch.float64, device="cuda")
+    ones = torch.ones((256, n, n), dtype=torch.float64, device="cuda") * c[:, None, None]
+    w, info = gpu_ops.eig_general_batched(ones)
+    assert int(info.abs().sum().item()) == 0
+    w = w.cpu().numpy()
+    top = np.abs(w).argmax(axis=1)
+    np.testing.assert_allclose(w[np.arange(256), top].real, 64 * c.cpu().numpy(), rtol=1e-13)
+    rest = np.sort(np.abs(w), axis=1)[:, :-1]
+    assert rest.max() < 1e-12
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    u = torch.randn((128, n, 1), generator=g, device="cuda", dtype=torch.float64)
+    v = torch.randn((128, 1, n), generator=g, device="cuda", dtype=torch.float64)
+    w, info = gpu_ops.eig_general_batched((u * v).contiguous())             # rank one: spectrum {v.u, 0 x 63}
+    assert int(info.abs().sum().item()) == 0
+    w = w.cpu().numpy()
+    dot = (v.squeeze(1) * u.squeeze(2)).sum(dim=1).cpu().numpy()
+    top = np.abs(w).argmax(axis=1)
+    scale = (u.norm(dim=(1, 2)) * v.norm(dim=(1, 2))).cpu().numpy()
+    assert np.max(np.abs(w[np.arange(128), top] - dot) / scale) < 1e-13
+    assert np.max(np.sort(np.abs(w), axis=1)[:, :-1] / scale[:, None]) < 1e-7      # 63-fold defective zero eigenvalue
+    nil = torch.triu(torch.randn((64, n, n), generator=g, device="cuda", dtype=torch.float64), 1)
+    w, info = gpu_ops.eig_general_batched(nil)
+    assert int(info.abs().sum().item()) == 0 and float(w.abs().max().item()) == 0.0   # exact zeros stay exact

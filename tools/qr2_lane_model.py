@@ -16,11 +16,17 @@ PAD = 80
 
 
 def coeffs(a0, a1, a2):
-    """larfg3_coeffs of the kernel: a column with |a|^2 < 2^-800 (the drivers scale the matrix to max |entry| in [1, 2))
-    gets the reflection diag(-1, 1, 1) instead of a reflector built from underflowed squares."""
+    """larfg3_coeffs of the kernel: a column with |a|^2 < 2^-800 is rescaled by a power of two first (xLARFG's rescaling;
+    u and t are scale-invariant), an exactly zero column gets the reflection diag(-1, 1, 1)."""
     nrm2 = a0 * a0 + (a2 * a2 + a1 * a1)
     if nrm2 < 2.0 ** -800:
-        a0, a1, a2, nrm2 = 1.0, 0.0, 0.0, 1.0
+        big = max(abs(a0), abs(a1), abs(a2))
+        if big > 0.0:
+            e = math.frexp(big)[1] - 1
+            a0, a1, a2 = math.ldexp(a0, -e), math.ldexp(a1, -e), math.ldexp(a2, -e)
+        else:
+            a0, a1, a2 = 1.0, 0.0, 0.0
+        nrm2 = a0 * a0 + (a2 * a2 + a1 * a1)
     rn = 1.0 / math.sqrt(nrm2)
     apn = abs(a0) + nrm2 * rn
     scal = math.copysign(1.0 / apn, a0)
@@ -147,7 +153,7 @@ def hqr_lanes(hin, stats):
     h = hp[:n, :n]
     ULP, SAFMIN = P1.ULP, P1.SAFMIN
     wr, wi = np.zeros(n), np.zeros(n)
-    smlnum = SAFMIN * (n / ULP)
+    smlnum = 1e-200        # the kernel's n = 64 drivers scale the matrix to max |entry| in [1, 2)
     i = n - 1
     kdefl = 0
     while i >= 0:

@@ -28,6 +28,9 @@ def kinds(nmat, n, cplx):
     gr = torch.triu(rnd(), -1) * (10.0 ** (-torch.rand((nmat, n, 1), generator=g, device="cuda", dtype=torch.float64) * 8))
     yield "graded-hessenberg", gr
     yield "skew*1e-160", (s - s.transpose(1, 2).conj()) * 1e-160
+    yield "constant", torch.ones_like(s) * (0.5 + torch.rand((nmat, 1, 1), generator=g, device="cuda", dtype=torch.float64))
+    r1 = rnd()
+    yield "rank-one", r1[:, :, :1] * r1[:, :1, :]
 
 
 out = {}
