@@ -19,10 +19,12 @@ namespace egs {
 
 // Element (i,j) of the wave's matrix lives at hm[i*sr + j*sc].  LDP > 0 fixes the pair-array leading dimension at
 // compile time (n = 64 -> 71) so that row / column neighbours become DS-instruction immediate offsets; LDP == 0 keeps
-// it in a register (any n <= 64).  TR selects the transposed member of a packed pair.
-template <int LDP, bool TR>
+// it in a register (any n <= 64).  TR selects the transposed member of a packed pair.  N = rows of the array (the fast
+// layouts clamp never-used lane indices to N - 1 so that every address stays inside the wave's own array).
+template <int LDP, bool TR, int N = 64>
 struct MatViewT {
     static constexpr bool kFast = LDP > 0;
+    static constexpr int kN = N;
     static constexpr int kSR = TR ? 1 : LDP, kSC = TR ? LDP : 1;   // compile-time strides of the fast layouts (LDP > 0)
     double* hm;
     int ld;
@@ -700,21 +702,31 @@ __device__ __forceinline__ void lds_read3x2(const double* p, const double* q, do
         : "memory");
 }
 
-// Predicated store of three doubles p[0], p[S1], p[2 S1] by the lanes with e <= thr (thr wave-uniform): v_cmpx writes
+// Predicated store of three doubles p[0], p[S1], p[2 S1] by the lanes with e <= thr (GE: e >= thr; thr wave-uniform): v_cmpx writes
 // EXEC directly, the stores run under it, EXEC goes back to all ones -- two instructions of overhead instead of the
 // compare + s_and_saveexec + s_cbranch_execz + s_or the compiler emits for `if (e <= thr) { ... }`, and no branch.
 // Only used where control flow is wave-uniform with all 64 lanes alive (the steady-state iterations of a sweep).
-template <int S1>
-__device__ __forceinline__ void lds_store3_where_le(int e, int thr, double* p, double v0, double v1, double v2) {
+template <int S1, bool GE>
+__device__ __forceinline__ void lds_store3_where(int e, int thr, double* p, double v0, double v1, double v2) {
     static_assert(2 * S1 < 256, "ds_write2_b64 offsets are 8-bit, in units of 8 bytes");
-    asm volatile(
-        "v_cmpx_ge_i32_e32 vcc, %1, %0\n\t"
-        "ds_write2_b64 %2, %3, %4 offset1:%6\n\t"
-        "ds_write_b64 %2, %5 offset:%7\n\t"
-        "s_mov_b64 exec, -1"
-        :
-        : "v"(e), "s"(thr), "v"((unsigned)(uintptr_t)p), "v"(v0), "v"(v1), "v"(v2), "n"(S1), "n"(2 * S1 * 8)
-        : "vcc", "memory");
+    if (GE)
+        asm volatile(
+            "v_cmpx_le_i32_e32 vcc, %1, %0\n\t"
+            "ds_write2_b64 %2, %3, %4 offset1:%6\n\t"
+            "ds_write_b64 %2, %5 offset:%7\n\t"
+            "s_mov_b64 exec, -1"
+            :
+            : "v"(e), "s"(thr), "v"((unsigned)(uintptr_t)p), "v"(v0), "v"(v1), "v"(v2), "n"(S1), "n"(2 * S1 * 8)
+            : "vcc", "memory");
+    else
+        asm volatile(
+            "v_cmpx_ge_i32_e32 vcc, %1, %0\n\t"
+            "ds_write2_b64 %2, %3, %4 offset1:%6\n\t"
+            "ds_write_b64 %2, %5 offset:%7\n\t"
+            "s_mov_b64 exec, -1"
+            :
+            : "v"(e), "s"(thr), "v"((unsigned)(uintptr_t)p), "v"(v0), "v"(v1), "v"(v2), "n"(S1), "n"(2 * S1 * 8)
+            : "vcc", "memory");
 }
 
 struct Qr2Lane {
@@ -723,8 +735,10 @@ struct Qr2Lane {
     double* bp;        // &H(k, k-1): the bulge column
     int inc_r, inc_c, inc_b;   // advance per iteration in doubles (0 while the group is parked)
     int d_r, d_c;      // element offset of the secondary column / row
-    int er;            // row pass:    primary valid <=> er <= L,  secondary <=> er <= L - 32
-    int ec0, ec1;      // column pass: primary valid <=> ec0 <= M, secondary <=> ec1 <= M
+    // validity in iteration t of the sweep -- every test compares a per-lane constant with the iteration counter itself,
+    // so the steady-state loop carries one scalar (the window thresholds L = Lbase - t, M = Mbase + t are folded in)
+    int er0, er1;      // row pass:    primary valid <=> t <= er0, secondary <=> t <= er1  (er1 = er0 - 32)
+    int ec0, ec1;      // column pass: primary valid <=> t >= ec0, secondary <=> t >= ec1
 };
 
 // One iteration: both groups advance their bulge by one row.
@@ -739,7 +753,7 @@ struct Qr2Lane {
 // phase in one batch behind the row stores.  (Left alone, the compiler sinks each sub-pass's loads into its predicated
 // store block: five serialised round trips per iteration.)  The empty asm statements pin the batches.
 template <bool GEN, bool R2, bool C2, class V>
-__device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, const bool first, const bool last,
+__device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int t, const bool first, const bool last,
                                          const bool top, const double v0, const double v1, const double v2) {
     constexpr int SR = V::kSR, SC = V::kSC;
     double a0, a1, a2, x0, x1, x2;
@@ -766,7 +780,7 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, c
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2));
     }
 #endif
-    int Lg = L;
+    int tg = t;
     if (GEN) {
         a0 = first ? v0 : a0;
         a1 = first ? v1 : a1;
@@ -775,7 +789,7 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, c
         if (R2) y2 = last ? 0.0 : y2;
         // a first step at the top of the window (m == l): column l-1 is outside it (H(l, l-1) = 0).  Below the top
         // (m > l) column m-1 takes part like any bulge column, which scales H(m, m-1) by (1 - t1) as xLAHQR does
-        Lg = (first && top) ? L - 1 : L;
+        tg = (first && top) ? t + 1 : t;
     }
     double t1, t2, t3, u1, u2;
     larfg3_coeffs(a0, a1, a2, t1, t2, t3, u1, u2);
@@ -789,8 +803,8 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, c
         const double sum = fma(u2, x2, fma(u1, x1, x0));
         const double n0 = fma(-sum, t1, x0), n1 = fma(-sum, t2, x1), n2 = fma(-sum, t3, x2);
         if (!GEN) {
-            lds_store3_where_le<SR>(S.er, Lg, S.rowp, n0, n1, n2);
-        } else if (S.er <= Lg) {
+            lds_store3_where<SR, true>(S.er0, t, S.rowp, n0, n1, n2);
+        } else if (S.er0 >= tg) {
             S.rowp[0] = n0;
             S.rowp[SR] = n1;
             if (!last) S.rowp[2 * SR] = n2;
@@ -800,8 +814,8 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, c
         const double sum = fma(u2, y2, fma(u1, y1, y0));
         const double n0 = fma(-sum, t1, y0), n1 = fma(-sum, t2, y1), n2 = fma(-sum, t3, y2);
         if (!GEN) {
-            lds_store3_where_le<SR>(S.er, Lg - 32, rp2, n0, n1, n2);
-        } else if (S.er <= Lg - 32) {
+            lds_store3_where<SR, true>(S.er1, t, rp2, n0, n1, n2);
+        } else if (S.er1 >= tg) {
             rp2[0] = n0;
             rp2[SR] = n1;
             if (!last) rp2[2 * SR] = n2;
@@ -833,8 +847,8 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, c
         const double sum = fma(u2, c2, fma(u1, c1, c0));
         const double n0 = fma(-sum, t1, c0), n1 = fma(-sum, t2, c1), n2 = fma(-sum, t3, c2);
         if (!GEN) {
-            lds_store3_where_le<SC>(S.ec0, M, S.colp, n0, n1, n2);
-        } else if (S.ec0 <= M) {
+            lds_store3_where<SC, false>(S.ec0, t, S.colp, n0, n1, n2);
+        } else if (S.ec0 <= t) {
             S.colp[0] = n0;
             S.colp[SC] = n1;
             if (!last) S.colp[2 * SC] = n2;
@@ -844,8 +858,8 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, c
         const double sum = fma(u2, d2, fma(u1, d1, d0));
         const double n0 = fma(-sum, t1, d0), n1 = fma(-sum, t2, d1), n2 = fma(-sum, t3, d2);
         if (!GEN) {
-            lds_store3_where_le<SC>(S.ec1, M, cp2, n0, n1, n2);
-        } else if (S.ec1 <= M) {
+            lds_store3_where<SC, false>(S.ec1, t, cp2, n0, n1, n2);
+        } else if (S.ec1 <= t) {
             cp2[0] = n0;
             cp2[SC] = n1;
             if (!last) cp2[2 * SC] = n2;
@@ -857,10 +871,10 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int L, const int M, c
     S.bp += (GEN && (first || last)) ? 0 : S.inc_b;   // bp starts at &H(m+1, m): the first step does not read the bulge
 }
 
-// steady-state iterations t0 <= t < t1 of one (R2, C2) segment: L = Lbase - t, M = Mbase + t
+// steady-state iterations t0 <= t < t1 of one (R2, C2) segment
 template <bool R2, bool C2, class V>
-__device__ __forceinline__ void qr2_segment(Qr2Lane& S, int t0, const int t1, const int Lbase, const int Mbase) {
-    for (int t = t0; t < t1; ++t) qr2_iter<false, R2, C2, V>(S, Lbase - t, Mbase + t, false, false, false, 0.0, 0.0, 0.0);
+__device__ __forceinline__ void qr2_segment(Qr2Lane& S, int t0, const int t1) {
+    for (int t = t0; t < t1; ++t) qr2_iter<false, R2, C2, V>(S, t, false, false, false, 0.0, 0.0, 0.0);
 }
 
 // One sweep over the window [l, i] from start row m with start vector (v0, v1, v2); (rt1r, rt1i, rt2r, rt2i) are the
@@ -880,25 +894,28 @@ __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, 
     const int nA = i - m;                                   // steps of one bulge: k = m .. i-1
     const int T = nA + (two ? kBulgeDist : 0);
     const int c1 = max(i - 31 + j, 0), c0 = max(i - 63 + j, 0);
-    const int r0 = min(l + j, 63), r1 = min(l + 32 + j, 63);
+    const int r0 = min(l + j, V::kN - 1), r1 = min(l + 32 + j, V::kN - 1);
     Qr2Lane S;
     S.rowp = &H.at(m, c1);
     S.colp = &H.at(r0, m);
     S.bp = &H.at(m + 1, m);
     S.d_r = (c0 - c1) * SC;
     S.d_c = (r1 - r0) * SR;
-    const int er_live = 31 - j - kBulgeDist * g;
-    const int ec0_live = (l + j <= i) ? j + kBulgeDist * g : kNever;
-    const int ec1_live = (l + 32 + j <= i) ? j + 32 + kBulgeDist * g : kNever;
+    // thresholds of iteration t:  L = i - (m + t) + 1 = Lbase - t,  M = m + t + 3 - l = Mbase + t
+    const int Lbase = nA + 1, Mbase = m + 3 - l;
+    // row pass:    31 - j - dist g      <= L  (primary; secondary: <= L - 32)  <=>  t <= er0 (er0 - 32)
+    // column pass: j (+ 32) + dist g    <= M                                   <=>  t >= ec0 (ec1)
+    const int er0_live = Lbase - (31 - j - kBulgeDist * g);
+    const int ec0_live = (l + j <= i) ? j + kBulgeDist * g - Mbase : kNever;
+    const int ec1_live = (l + 32 + j <= i) ? j + 32 + kBulgeDist * g - Mbase : kNever;
     const bool liveA = g == 0;
-    S.er = liveA ? er_live : kNever;
+    S.er0 = liveA ? er0_live : -kNever;
+    S.er1 = liveA ? er0_live - 32 : -kNever;
     S.ec0 = liveA ? ec0_live : kNever;
     S.ec1 = liveA ? ec1_live : kNever;
     S.inc_r = liveA ? SR : 0;
     S.inc_c = liveA ? SC : 0;
     S.inc_b = liveA ? SR + SC : 0;
-    // thresholds of iteration t:  L = i - (m + t) + 1 = Lbase - t,  M = m + t + 3 - l = Mbase + t
-    const int Lbase = nA + 1, Mbase = m + 3 - l;
     const int tR = Lbase - (32 - kBulgeDist) + 1;            // R2 holds for t < tR   (L >= 32 - kBulgeDist: group 1, lane 31)
     const int tC = 32 - Mbase;                              // C2 holds for t >= tC  (M >= 32)
     // the iterations in which a group starts or ends (at most four, in increasing order of t)
@@ -918,11 +935,11 @@ __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, 
             if (r2) e = min(e, tR);
             if (!c2) e = min(e, tC);
             if (r2) {
-                if (c2) qr2_segment<true, true, V>(S, t, e, Lbase, Mbase);
-                else qr2_segment<true, false, V>(S, t, e, Lbase, Mbase);
+                if (c2) qr2_segment<true, true, V>(S, t, e);
+                else qr2_segment<true, false, V>(S, t, e);
             } else {
-                if (c2) qr2_segment<false, true, V>(S, t, e, Lbase, Mbase);
-                else qr2_segment<false, false, V>(S, t, e, Lbase, Mbase);
+                if (c2) qr2_segment<false, true, V>(S, t, e);
+                else qr2_segment<false, false, V>(S, t, e);
             }
             QRP(P.nfast += e - t;)
             t = e;
@@ -945,7 +962,8 @@ __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, 
             v0 *= rs;
             v1 *= rs;
             v2 *= rs;
-            S.er = liveA ? S.er : er_live;
+            S.er0 = liveA ? S.er0 : er0_live;
+            S.er1 = liveA ? S.er1 : er0_live - 32;
             S.ec0 = liveA ? S.ec0 : ec0_live;
             S.ec1 = liveA ? S.ec1 : ec1_live;
             S.inc_r = liveA ? S.inc_r : SR;
@@ -956,14 +974,15 @@ __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, 
             const bool first = liveA ? fA : fB, last = liveA ? lA : lB;
             const bool r2 = t < tR, c2 = t >= tC;
             if (r2) {
-                if (c2) qr2_iter<true, true, true, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
-                else qr2_iter<true, true, false, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
+                if (c2) qr2_iter<true, true, true, V>(S, t, first, last, two, v0, v1, v2);
+                else qr2_iter<true, true, false, V>(S, t, first, last, two, v0, v1, v2);
             } else {
-                if (c2) qr2_iter<true, false, true, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
-                else qr2_iter<true, false, false, V>(S, Lbase - t, Mbase + t, first, last, two, v0, v1, v2);
+                if (c2) qr2_iter<true, false, true, V>(S, t, first, last, two, v0, v1, v2);
+                else qr2_iter<true, false, false, V>(S, t, first, last, two, v0, v1, v2);
             }
             const bool park = last;
-            S.er = park ? kNever : S.er;
+            S.er0 = park ? -kNever : S.er0;
+            S.er1 = park ? -kNever : S.er1;
             S.ec0 = park ? kNever : S.ec0;
             S.ec1 = park ? kNever : S.ec1;
             S.inc_r = park ? 0 : S.inc_r;
@@ -975,16 +994,22 @@ __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, 
     }
 }
 
+// Returns 0 when the whole spectrum has been written (or the iteration failed: info != 0), otherwise -- stop_below > 0 --
+// the order r = i + 1 <= stop_below of the leading block that is still to be solved: eigenvalues r .. n-1 are written,
+// rows / columns 0 .. r-1 of H hold the unreduced Hessenberg block (see hqr_tail_kernel).  n_it = the order the
+// iteration limit is derived from (that of the original matrix).
 template <class V>
-__device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
-                         int32_t* __restrict__ info_out, const double rescale) {
+__device__ __forceinline__ int hqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
+                                        int32_t* __restrict__ info_out, const double rescale, const int stop_below = 0,
+                                        const int n_it = 0) {
     const double ulp = 2.220446049250313e-16;                      // dlamch('P')
     const double safmin = 2.2250738585072014e-308;
     // n = 64 layouts: the matrix was scaled to max |entry| in [1, 2), so a sub-diagonal entry below 1e-200 is negligible
     // ABSOLUTELY (xLAHQR's smlnum is 6e-291: with a zero diagonal its relative tests never fire and the iteration would
     // chase blocks all the way down into the underflow range)
     const double smlnum = V::kFast ? 1e-200 : safmin * ((double)n / ulp);
-    const int itmax = 30 * (n > 10 ? n : 10);
+    const int nit = n_it > 0 ? n_it : n;
+    const int itmax = 30 * (nit > 10 ? nit : 10);
     const int kexsh = 10;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
 
@@ -992,7 +1017,7 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
     int i = n - 1;
     int kdefl = 0;
     QRP(QrProf P = {0, 0, 0, 0, 0, 0, 0}; long long tscan = qr_now(); const long long tstart = tscan;)
-    while (i >= 0) {
+    while (i >= stop_below && i >= 0) {
         int l = 0;
         bool converged = false;
         for (int its = 0; its <= itmax; ++its) {
@@ -1005,7 +1030,9 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
                 // Lane k fetches its neighbourhood of them in ONE batch (clamped, always-valid addresses) together with
                 // the trailing 2 x 2 block, so the preamble of a sweep is one LDS round trip instead of one per
                 // section and per nested condition (it was 3.1 k cycles per sweep, 13 % of the QR stage).
-                const int k = lane, km = (k > 0) ? k - 1 : 0, kp = (k < 63) ? k + 1 : 63, kp2 = (k < 62) ? k + 2 : 63;
+                constexpr int kLast = V::kN - 1;
+                const int k = (lane < kLast) ? lane : kLast, km = (k > 0) ? k - 1 : 0, kp = (k < kLast) ? k + 1 : kLast,
+                          kp2 = (k < kLast - 1) ? k + 2 : kLast;
                 const int i1 = (i > 0) ? i - 1 : 0;
                 const double d0 = H.at(k, k), dm = H.at(km, km), dp = H.at(kp, kp);
                 const double s0 = H.at(k, km), s1 = H.at(kp, k), s2 = H.at(kp2, kp);
@@ -1291,8 +1318,10 @@ __device__ __forceinline__ void hqr_wave(const V H, const int n, const int lane,
         }
     }
     if (lane == 0) *info_out = info;
+    const int rem = (info == 0 && i >= 0) ? i + 1 : 0;
     QRP(if (blockIdx.x == 0 && threadIdx.x == 0) printf("QRPROF total %lld scan %lld setup %lld gen %lld (%lld) fast %lld (%lld) sweeps %lld\n",
                                                           qr_now() - tstart, P.scan, P.setup, P.gen, P.ngen, P.fast, P.nfast, P.nsweep);)
+    return rem;
 }
 
 // Packed-pair LDS layout of the QR kernel: array of n rows x ldp columns per pair.
@@ -1330,8 +1359,11 @@ __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ sr
 // N64 = true: n == 64, only the two compile-time layouts (two-bulge sweep); false: any n < 64 (run-time leading dimension,
 // single-bulge sweep).  Two kernels instead of four inlined copies of hqr_wave in one: the scalar state of each fits
 // the SGPR file (the single kernel of rounds 1-2 spilled 257 SGPRs).
+#ifndef EGS_HQR_MIN_BLOCKS
+#define EGS_HQR_MIN_BLOCKS 1
+#endif
 template <bool N64>
-__global__ __launch_bounds__(512) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
+__global__ __launch_bounds__(512, EGS_HQR_MIN_BLOCKS) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
                                                        double* __restrict__ w, int32_t* __restrict__ info,
                                                        int waves_per_block, int scaled,
                                                        unsigned long long* __restrict__ next_mat) {
@@ -1389,6 +1421,103 @@ constexpr int kFusedWaves = 4;                                   // 2 pairs per 
 constexpr int kFusedPairDoubles = 64 * kLd64;                    // hqr_pair_ld(64)
 constexpr size_t kFusedLds = (size_t)(2 * kFusedPairDoubles + kFusedWaves * kRegVec) * sizeof(double);
 
+// ---------------------------------------------------------------------------------------------------
+// Two phases (n = 64).  A 64 x 64 Hessenberg matrix takes 18.7 KB of LDS, so only two waves fit a SIMD, and at two per
+// SIMD a wave spends half its life waiting on its own dependent chain (profiles/r03_rejected_sweep_variants.md: the
+// occupancy experiment).  But the iteration deflates from the bottom: once the eigenvalues at positions >= kTailN
+// are out, what is left is a kTailN x kTailN problem that needs (kTailN / 64)^2 of the LDS -- and it is about half of the
+// work (an iteration costs the same whatever the window's length; their number goes with the window's end).  So the
+// fused kernel stops a matrix when its active block ends below row kTailN, writes that block (with the rounding-level
+// entries a chase leaves on the two diagonals below the sub-diagonal: the continuation is bit-identical to the
+// one-kernel iteration) plus its order and scaling exponent to a hand-off record in the workspace, and
+// hqr_tail_kernel finishes all of them at twice the occupancy (kTailN = 44: 16 waves per CU).
+// Hand-off record: kTailN x kTailN doubles, row-major, then {order of the remaining block (0 = nothing left), exponent}.
+// ---------------------------------------------------------------------------------------------------
+#ifndef EGS_TAIL_N
+#define EGS_TAIL_N 44
+#endif
+constexpr int kTailN = EGS_TAIL_N;
+static_assert(kTailN % 2 == 0 && kTailN >= 34 && kTailN <= 56, "tail order: even (odd leading dimension), > 32 + bulge distance");
+constexpr int kTailLd = kTailN + 9;                              // odd; diagonal stride kTailLd + 1 spreads over >= 16 banks
+constexpr int kTailRec = kTailN * kTailN + 2;                    // doubles per hand-off record
+#ifndef EGS_TAIL_WAVES
+#define EGS_TAIL_WAVES 4
+#endif
+constexpr int kTailWaves = EGS_TAIL_WAVES;                       // 2 pairs per workgroup
+constexpr int kTailPairDoubles = kTailN * kTailLd;
+constexpr size_t kTailLds = (size_t)(kTailWaves / 2 * kTailPairDoubles) * sizeof(double) + 1024;   // + the order-2 step's over-read
+
+// Only the part of the record a continuation reads is moved: rows r <= c + 3 of columns c < order (the Hessenberg part
+// and the two diagonals below it) -- about half of the order^2 block, ~9 KB per matrix each way.
+template <class V>
+__device__ __forceinline__ void tail_handoff_write(const V H, const int rem, const int e, double* __restrict__ rec,
+                                                   const int lane) {
+    const int c = (lane < kTailN) ? lane : kTailN - 1;
+    for (int r = 0; r < rem; ++r) {
+        const double v = H.at(r, c);
+        if (lane < rem && r <= lane + 3) rec[r * kTailN + lane] = v;
+    }
+    if (lane == 0) {
+        rec[kTailN * kTailN] = (double)rem;
+        rec[kTailN * kTailN + 1] = (double)e;
+    }
+}
+
+template <class V>
+__device__ __forceinline__ void tail_handoff_read(const V H, const int rem, const double* __restrict__ rec, const int lane) {
+    int r = 0;
+    for (; r + 4 <= rem; r += 4) {
+        double t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = (lane < rem && r + u <= lane + 3) ? rec[(r + u) * kTailN + lane] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (lane < rem && r + u <= lane + 3) H.at(r + u, lane) = t[u];
+    }
+    for (; r < rem; ++r)
+        if (lane < rem && r <= lane + 3) H.at(r, lane) = rec[r * kTailN + lane];
+}
+
+__global__ __launch_bounds__(kTailWaves* kWave, 4) void hqr_tail_kernel(const double* __restrict__ handoff, int64_t nmat,
+                                                                         double* __restrict__ w, int32_t* __restrict__ info,
+                                                                         unsigned long long* __restrict__ next_mat) {
+    extern __shared__ __attribute__((aligned(16))) double smem_tail[];
+    const int lane0 = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    double* base = smem_tail + (size_t)(wave >> 1) * kTailPairDoubles;
+    const int64_t first = (int64_t)blockIdx.x * kTailWaves + wave;
+    const int64_t stride0 = (int64_t)gridDim.x * kTailWaves;
+    for (int64_t mat = first; mat < nmat;) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const double* rec = handoff + mat * (int64_t)kTailRec;
+        const int rem = __builtin_amdgcn_readfirstlane((int)rec[kTailN * kTailN]);
+        if (rem > 0 && rem <= kTailN) {
+            const int e = __builtin_amdgcn_readfirstlane((int)rec[kTailN * kTailN + 1]);
+            const double rescale = (e != 0) ? scalbn(1.0, e) : 1.0;
+            double* wo = w + mat * 128;
+            if ((wave & 1) == 0) {
+                const MatViewT<kTailLd, false, kTailN> H{base + 7, kTailLd};
+                tail_handoff_read(H, rem, rec, lane);
+                wave_lds_sync();
+                hqr_wave(H, rem, lane, wo, info + mat, rescale, 0, 64);
+            } else {
+                const MatViewT<kTailLd, true, kTailN> H{base, kTailLd};
+                tail_handoff_read(H, rem, rec, lane);
+                wave_lds_sync();
+                hqr_wave(H, rem, lane, wo, info + mat, rescale, 0, 64);
+            }
+        }
+        wave_lds_sync();
+        if (next_mat == nullptr) break;
+        unsigned long long nx = 0ULL;
+        if (lane == 0) nx = atomicAdd(next_mat, 1ULL);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(nx & 0xffffffffULL));
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(nx >> 32));
+        mat = stride0 + (int64_t)(((unsigned long long)hi << 32) | lo);
+    }
+}
+
 template <class V>
 __device__ __forceinline__ void store_hessenberg(const V H, const double (&A)[16][4], const RegLane& L) {
     // the Hessenberg part plus the two extra sub-diagonals a bulge may touch (zeros)
@@ -1403,7 +1532,8 @@ __device__ __forceinline__ void store_hessenberg(const V H, const double (&A)[16
 
 __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
     const double* __restrict__ a, int64_t nmat, int lda, int64_t stride, double* __restrict__ w,
-    int32_t* __restrict__ info, double* __restrict__ scratch, int balance, unsigned long long* __restrict__ next_mat) {
+    int32_t* __restrict__ info, double* __restrict__ scratch, int balance, unsigned long long* __restrict__ next_mat,
+    double* __restrict__ handoff) {
     extern __shared__ __attribute__((aligned(16))) double smem_fused[];
     constexpr int n = 64, ldp = kLd64;
     const int lane0 = threadIdx.x & (kWave - 1);
@@ -1430,19 +1560,25 @@ __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
         if (e == kNonFinite) {        // like numpy.linalg.eigvals, non-finite input is an error, not a spectrum
             const double qnan = __longlong_as_double(0x7ff8000000000000LL);
             for (int j = lane; j < 2 * n; j += kWave) wo[j] = qnan;
-            if (lane == 0) info[mat] = n;
+            if (lane == 0) {
+                info[mat] = n;
+                if (handoff != nullptr) handoff[mat * (int64_t)kTailRec + kTailN * kTailN] = 0.0;
+            }
         } else {
             const double rescale = (e != 0) ? scalbn(1.0, e) : 1.0;
+            const int stop_below = (handoff != nullptr) ? kTailN : 0;
             if ((wave & 1) == 0) {
                 const MatViewT<kLd64, false> H{base + 7, ldp};
                 store_hessenberg(H, A, L);
                 wave_lds_sync();
-                hqr_wave(H, n, lane, wo, info + mat, rescale);
+                const int rem = hqr_wave(H, n, lane, wo, info + mat, rescale, stop_below);
+                if (handoff != nullptr) tail_handoff_write(H, rem, e, handoff + mat * (int64_t)kTailRec, lane);
             } else {
                 const MatViewT<kLd64, true> H{base, ldp};
                 store_hessenberg(H, A, L);
                 wave_lds_sync();
-                hqr_wave(H, n, lane, wo, info + mat, rescale);
+                const int rem = hqr_wave(H, n, lane, wo, info + mat, rescale, stop_below);
+                if (handoff != nullptr) tail_handoff_write(H, rem, e, handoff + mat * (int64_t)kTailRec, lane);
             }
         }
         wave_lds_sync();                                          // this matrix's LDS traffic is complete before the next one
@@ -1458,11 +1594,28 @@ __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
 // ---------------------------------------------------------------------------------------------------
 // host-side launcher
 // ---------------------------------------------------------------------------------------------------
+// waves of the fused kernel's grid: one resident set (two workgroups per CU), fewer for small batches
+static int64_t fused_resident_waves(int64_t nmat) {
+    int64_t blocks = (nmat + kFusedWaves - 1) / kFusedWaves;
+    const int64_t resident = (int64_t)current_device_cus() * (int64_t)((160 * 1024) / kFusedLds);
+    if (blocks > resident) blocks = resident;
+    return blocks * kFusedWaves;
+}
+
 size_t eig_real_lds_workspace_bytes(int64_t nmat, int n) {
     // Hessenberg matrices of one chunk.  64 Ki matrices per launch (2 GiB at n = 64): every launch ends with a tail in
     // which the slowest matrices keep a few CUs busy; 4x fewer launches than with 16 Ki chunks measured 2.6 % faster
     const int64_t chunk = nmat < 65536 ? nmat : 65536;
-    return (size_t)chunk * n * n * sizeof(double) + 256;          // + the work-queue counter of the QR kernel
+    size_t b = (size_t)chunk * n * n * sizeof(double) + 256;      // + the work-queue counter of the QR kernel
+    if (n == 64 && nmat >= kFusedWaves) {
+        // two-phase solver: one scratch slot per resident wave, one hand-off record per matrix (up to 2^20 of them per
+        // pass: 16 GB; larger batches run in several passes), two work-queue counters
+        const int64_t waves = fused_resident_waves(nmat);
+        const int64_t recs = nmat < (1 << 20) ? nmat : (1 << 20);
+        const size_t two = (size_t)waves * n * n * sizeof(double) + (size_t)recs * kTailRec * sizeof(double) + 256;
+        if (two > b) b = two;
+    }
+    return b;
 }
 
 static int set_lds_attrs() {
@@ -1557,7 +1710,39 @@ int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t s
     if (n == 64 && chunk >= kFusedWaves && !getenv("EGS_EIG_UNFUSED")) {     // A/B switch: the two-kernel path below
         EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eig_real64_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hqr_tail_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         const int cus = current_device_cus();
+        const int balance = getenv("EGS_NO_BALANCE") ? 0 : 1;
+        // Two phases when the workspace holds a scratch slot per wave of the grid plus hand-off records for a useful
+        // number of matrices (egs_eig_workspace_bytes asks for all of them); otherwise the one-kernel form.
+        const int64_t waves2 = fused_resident_waves(nmat);
+        const size_t slots2 = (size_t)waves2 * per_mat, rec_bytes = (size_t)kTailRec * sizeof(double);
+        int64_t pass = workspace_bytes > slots2 + 256 ? (int64_t)((workspace_bytes - slots2 - 256) / rec_bytes) : 0;
+        if (pass > nmat) pass = nmat;
+        const int64_t pass_min = nmat < 32768 ? nmat : 32768;
+        if (pass >= pass_min && !getenv("EGS_EIG_ONE_PHASE")) {
+            char* wsb = reinterpret_cast<char*>(workspace);
+            double* hand = reinterpret_cast<double*>(wsb + slots2);
+            unsigned long long* queues = reinterpret_cast<unsigned long long*>(wsb + slots2 + (size_t)pass * rec_bytes);
+            const int64_t tail_resident = (int64_t)cus * (int64_t)((160 * 1024) / kTailLds);
+            for (int64_t m0 = 0; m0 < nmat; m0 += pass) {
+                const int64_t cnt = (nmat - m0 < pass) ? (nmat - m0) : pass;
+                int64_t blocks = (cnt + kFusedWaves - 1) / kFusedWaves;
+                if (blocks * kFusedWaves > waves2) blocks = waves2 / kFusedWaves;
+                int64_t tblocks = (cnt + kTailWaves - 1) / kTailWaves;
+                if (tblocks > tail_resident) tblocks = tail_resident;
+                EGS_HIP(hipMemsetAsync(queues, 0, 2 * sizeof(unsigned long long), stream));
+                hipLaunchKernelGGL(eig_real64_kernel, dim3((unsigned)blocks), dim3(kFusedWaves * kWave), kFusedLds, stream,
+                                   a + m0 * stride, cnt, lda, stride, w + m0 * 2 * (int64_t)n, info + m0, hws, balance,
+                                   queues, hand);
+                EGS_LAUNCH_CHECK();
+                hipLaunchKernelGGL(hqr_tail_kernel, dim3((unsigned)tblocks), dim3(kTailWaves * kWave), kTailLds, stream,
+                                   hand, cnt, w + m0 * 2 * (int64_t)n, info + m0, queues + 1);
+                EGS_LAUNCH_CHECK();
+            }
+            return 0;
+        }
         // one resident set of waves (two workgroups per CU) fed by a work queue; every wave owns one scratch slot of the
         // workspace, so the grid never holds more waves than the workspace has slots
         int64_t blocks = (nmat + kFusedWaves - 1) / kFusedWaves;
@@ -1569,9 +1754,8 @@ int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t s
             queue = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(workspace) + (size_t)chunk * per_mat);
             EGS_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream));
         }
-        const int balance = getenv("EGS_NO_BALANCE") ? 0 : 1;
         hipLaunchKernelGGL(eig_real64_kernel, dim3((unsigned)blocks), dim3(kFusedWaves * kWave), kFusedLds, stream, a, nmat,
-                           lda, stride, w, info, hws, balance, queue);
+                           lda, stride, w, info, hws, balance, queue, static_cast<double*>(nullptr));
         EGS_LAUNCH_CHECK();
         return 0;
     }

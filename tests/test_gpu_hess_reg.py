@@ -129,6 +129,49 @@ def test_fused_kernel_equals_the_two_kernel_path(gpu_ops, monkeypatch):
     assert torch.equal(torch.view_as_real(w_small), torch.view_as_real(w2)) and torch.equal(info_small, info2)
 
 
+def test_two_phase_solver_equals_the_one_kernel_iteration(gpu_ops, monkeypatch):
+    """The n = 64 solver hands a matrix over to hqr_tail_kernel once its active block ends below row 44 (twice the
+    occupancy for the second half of the iteration).  The continuation is the same arithmetic: spectra and info are
+    bit-identical to the one-kernel form (EGS_EIG_ONE_PHASE) on Gaussian, prescribed-spectrum, triangular (every
+    eigenvalue deflates at once: the hand-over happens in the middle of a run of deflations), zero, reducible and
+    non-finite matrices; also with a workspace that only holds records for part of the batch (several passes) and at
+    the float32 entry."""
+    from test_gpu_parity import known_spectrum_real
+    rng = np.random.default_rng(647)
+    a = rng.standard_normal((2500, 64, 64))
+    a[100:600] = known_spectrum_real(rng, 500, 64)[0]
+    a[600:700] = np.triu(a[600:700])
+    a[700:720] = 0.0
+    a[720:760, 50:, :50] = 0.0                     # block triangular: the trailing 14 x 14 block is solved first
+    a[760:800, 30:, :30] = 0.0                     # ... a 34 x 34 block: the leading 30 x 30 one goes to the tail kernel
+    a[800] = np.nan
+    a[801, 3, 5] = np.inf
+    a[802:840] *= 1e-170
+    a[840:880] *= 1e150
+    ad = dev(a)
+    w, info = gpu_ops.eig_general_batched(ad)
+    w32, info32 = gpu_ops.eig_general_batched(ad[:500].to(torch.float32))
+    # a workspace with hand-off records for 33000 of 40000 matrices: two passes (a pass is at least 32768 matrices)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(648)
+    big = torch.randn((40000, 64, 64), generator=gen, device="cuda", dtype=torch.float64)
+    slots = gpu_ops.device_props(0)["compute_units"] * 8 * 64 * 64 * 8
+    part = torch.empty(slots + 33000 * (44 * 44 + 2) * 8 + 256, dtype=torch.uint8, device="cuda")
+    w_part, info_part = gpu_ops.eig_general_batched(big, workspace=part)
+    monkeypatch.setenv("EGS_EIG_ONE_PHASE", "1")
+    w1, info1 = gpu_ops.eig_general_batched(ad)
+    w1_32, info1_32 = gpu_ops.eig_general_batched(ad[:500].to(torch.float32))
+    w1_big, info1_big = gpu_ops.eig_general_batched(big)
+    monkeypatch.delenv("EGS_EIG_ONE_PHASE")
+    same = lambda x, y: torch.equal(torch.view_as_real(x).view(torch.int64), torch.view_as_real(y).view(torch.int64))
+    assert same(w, w1) and torch.equal(info, info1)
+    assert same(w_part, w1_big) and torch.equal(info_part, info1_big) and int(info_part.abs().sum().item()) == 0
+    assert same(w32, w1_32) and torch.equal(info32, info1_32)
+    assert int(info[800].item()) == 64 and int(info[801].item()) == 64 and int(info.abs().sum().item()) == 128
+    assert O.max_abs_dlambda(w.cpu().numpy()[:100], np.linalg.eigvals(a[:100])) < 1e-11
+    assert O.max_abs_dlambda(w.cpu().numpy()[720:800], np.linalg.eigvals(a[720:800])) < 1e-11
+
+
 @pytest.mark.parametrize("nmat", [1, 2, 3, 5, 9])
 def test_tiny_batches(gpu_ops, nmat):
     """Fewer matrices than a workgroup has waves, and ragged last workgroups (waves without a matrix leave at once)."""

@@ -32,8 +32,12 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_workspace_queries_are_host_only(pkg):
     lib = pkg._capi.lib()
     c = pkg._capi
-    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 524288, 64) == 65536 * 64 * 64 * 8 + 256   # chunked Hessenberg scratch + queue
-    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 10, 64) == 10 * 64 * 64 * 8 + 256
+    # real n = 64, two-phase solver: a scratch slot per resident wave (256 CUs assumed without a device: 2048 waves), a
+    # hand-off record of 44 * 44 + 2 doubles per matrix, the queue counters
+    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 524288, 64) == 2048 * 64 * 64 * 8 + 524288 * (44 * 44 + 2) * 8 + 256
+    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 10, 64) == 12 * 64 * 64 * 8 + 10 * (44 * 44 + 2) * 8 + 256
+    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 3, 64) == 3 * 64 * 64 * 8 + 256            # below one workgroup: two-kernel path
+    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 10, 48) == 10 * 48 * 48 * 8 + 256           # n < 64: Hessenberg scratch + queue
     assert lib.egs_eig_workspace_bytes(c.EGS_C128, 768, 256) == 768 * 256 * 256 * 16     # workgroup path: full copy
     assert lib.egs_eig_workspace_bytes(c.EGS_C128, 768, 64) == 768 * 64 * 64 * 16       # Hessenberg hand-over
     assert lib.egs_eig_workspace_bytes(c.EGS_C128, 10, 96) == 10 * 96 * 96 * 16         # level-3 path: working copy

