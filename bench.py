@@ -185,9 +185,11 @@ def main():
     value = nmat * world / (elapsed / args.steps)
 
     # ---- per-kernel timing (HIP events on the launch stream) for the roofline object ----
-    # n = 64: the step is ONE launch of the fused kernel (eig_real64_kernel: Hessenberg reduction in registers + QR in
-    # LDS per wave, whole batch behind a work queue); ops launches on torch's current stream, which is the stream the
-    # events are recorded on.  Other orders: the two-kernel path, timed per stage below.
+    # n = 64: the step is one launch of the fused kernel (eig_real64_kernel: Hessenberg reduction in registers + QR in
+    # LDS per wave, whole batch behind a work queue) followed by one of hqr_tail_kernel, which finishes every matrix
+    # from the point where its active block fits a 44 x 44 array (twice the occupancy); the events bracket the pair.
+    # ops launches on torch's current stream, which is the stream the events are recorded on.  Other orders: the
+    # two-kernel path, timed per stage below.
     import ctypes
     lib = pkg._capi.lib()
     fused = (n == 64) and not os.environ.get("EGS_EIG_UNFUSED")
@@ -236,10 +238,12 @@ def main():
                                   "frac": qr_flops / (hq_avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
               "matrices_per_launch": chunk, "launches_timed": nlaunch}
     if fused:
-        kname, per_launch, k_ms = "eig_real64_kernel", nmat, float(np.mean(fused_ms))
+        kname, per_launch, k_ms = N64_KERNELS, nmat, float(np.mean(fused_ms))
         k_flops = (40.0 / 3.0) * n ** 3 * per_launch
         note = ("fp64 (vector = matrix peak); algorithmic (40/3) n^3 flops per matrix (Hessenberg (10/3) n^3 + QR 10 n^3), "
-                "%d matrices per launch; `two_kernel_stages` times the same two stages as separate kernels" % per_launch)
+                "%d matrices per launch; avg_launch_ms = the two phases of the solver back to back (rocprofv3: the sum of "
+                "the two kernels' average durations); `two_kernel_stages` times Hessenberg reduction and QR iteration "
+                "as separate kernels" % per_launch)
     else:
         kname, per_launch, k_ms = "hqr_real_kernel", chunk, hq_avg
         k_flops = qr_flops
@@ -320,8 +324,11 @@ def rehearse_launch(args, world, rank):
                           "dist_backend": "gloo" if world > 1 else None, "rehearsal": True, "gather_ok": ok}))
 
 
+N64_KERNELS = "eig_real64_kernel + hqr_tail_kernel"      # the two phases of the n = 64 solver (one step = one launch of each)
 KERNEL_SOURCES = {      # the files a kernel is compiled from; their hash ties a PMC measurement to a build
+    N64_KERNELS: ("eig_real_lds.hip", "hess_reg.h", "egs_common.h"),
     "eig_real64_kernel": ("eig_real_lds.hip", "hess_reg.h", "egs_common.h"),
+    "hqr_tail_kernel": ("eig_real_lds.hip", "egs_common.h"),
     "hqr_real_kernel": ("eig_real_lds.hip", "egs_common.h"),
 }
 

@@ -1359,11 +1359,11 @@ __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ sr
 // N64 = true: n == 64, only the two compile-time layouts (two-bulge sweep); false: any n < 64 (run-time leading dimension,
 // single-bulge sweep).  Two kernels instead of four inlined copies of hqr_wave in one: the scalar state of each fits
 // the SGPR file (the single kernel of rounds 1-2 spilled 257 SGPRs).
-#ifndef EGS_HQR_MIN_BLOCKS
-#define EGS_HQR_MIN_BLOCKS 1
+#ifndef EGS_HQR_MIN_WAVES_PER_EU
+#define EGS_HQR_MIN_WAVES_PER_EU 1
 #endif
 template <bool N64>
-__global__ __launch_bounds__(512, EGS_HQR_MIN_BLOCKS) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
+__global__ __launch_bounds__(512, EGS_HQR_MIN_WAVES_PER_EU) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
                                                        double* __restrict__ w, int32_t* __restrict__ info,
                                                        int waves_per_block, int scaled,
                                                        unsigned long long* __restrict__ next_mat) {

@@ -29,7 +29,7 @@ def test_bench_line_schema_and_consistency():
     # value = matrices per second of the timed steps
     assert abs(d["value"] - nmat / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["kernel"] == "eig_real64_kernel" and r["bound"] in ("hbm", "mfma") and r["unit"] == "TFLOP/s"
+    assert r["kernel"] == "eig_real64_kernel + hqr_tail_kernel" and r["bound"] in ("hbm", "mfma") and r["unit"] == "TFLOP/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # achieved = algorithmic flops per launch / measured launch time: (40/3) n^3 per matrix
     want = (40.0 / 3.0) * 64 ** 3 * nmat / (r["avg_launch_ms"] * 1e-3) / 1e12

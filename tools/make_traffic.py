@@ -40,6 +40,18 @@ def main():
             ent["algorithmic_bytes_per_launch"] = algo[base]
             ent["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / algo[base]
         out["kernels"][short] = ent
+    # the n = 64 solver is two kernels per step (bench.N64_KERNELS): their sum is what bench.py's roofline object quotes
+    parts = [p.strip() for p in bench.N64_KERNELS.split("+")]
+    if all(p in out["kernels"] for p in parts):
+        tot = sum(out["kernels"][p]["hbm_bytes_per_launch"] for p in parts)
+        a = algo["eig_real64_kernel"]
+        out["kernels"][bench.N64_KERNELS] = {
+            "launches": out["kernels"][parts[0]]["launches"], "hbm_bytes_per_launch": tot, "matrices_per_launch": nmat,
+            "hbm_bytes_per_matrix": tot / nmat, "algorithmic_bytes_per_launch": a, "traffic_over_algorithmic": tot / a,
+            "source_sha": bench.kernel_source_sha(bench.N64_KERNELS),
+            "note": "includes the hand-off records between the two phases (rows r <= c + 3 of a block of order <= 44, "
+                    "written by the first kernel and read by the second): a deliberate trade of ~1 % of HBM time for "
+                    "twice the occupancy in the second half of the iteration"}
     dst = os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)
     json.dump(out, open(dst, "w"), indent=1)
     print("wrote", dst, "with", len(out["kernels"]), "kernels")
