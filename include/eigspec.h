@@ -86,10 +86,13 @@ int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const do
  *   info   : int32[nmat]; 0 = converged, k > 0 = QR failed to deflate with k eigenvalues outstanding
  *            (their slots hold NaN), as LAPACK's xHSEQR info.
  *   workspace : device scratch of egs_eig_workspace_bytes(dtype, nmat, n) bytes, 256-byte aligned.
- * Real n = 64 (BASELINE config C2) runs one fused kernel: per wavefront the Hessenberg reduction with the matrix in
- * registers, then the QR iteration in LDS, the whole batch behind one work queue; the workspace then only provides a
- * 32 KB scratch slot per resident wavefront (a smaller workspace than the query's value is accepted there: it limits the
- * number of resident wavefronts, at least 4 slots + 256 bytes).  Other n <= 64, real or complex, run LDS-resident in two
+ * Real n = 64 (BASELINE config C2) runs a fused kernel: per wavefront the Hessenberg reduction with the matrix in
+ * registers, then the QR iteration in LDS, the whole batch behind one work queue; once a matrix's active block ends below
+ * row 44 it is handed over (a 15.5 KB record per matrix in the workspace) to a second kernel that finishes it at twice the
+ * occupancy -- same arithmetic, bit-identical spectra.  The workspace provides a 32 KB scratch slot per resident wavefront
+ * plus those records; a smaller workspace than the query's value is accepted: records for >= min(nmat, 32768) matrices
+ * give several passes, less gives the one-kernel form, which only needs the slots (it limits the number of resident
+ * wavefronts, at least 4 slots + 256 bytes).  Other n <= 64, real or complex, run LDS-resident in two
  * kernels (one wavefront per matrix, Hessenberg matrices of a chunk in the workspace); larger n (<= 1024; the reference's S4
  * state_dim 128 / 512 and config C5's 256) run the level-3 path: blocked Householder reduction with fp64 matrix-core panel
  * updates, then small-bulge multishift QR (one workgroup of 16 wavefronts per matrix, working copy in the workspace).
