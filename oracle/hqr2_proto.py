@@ -116,7 +116,7 @@ class _Bulge:
     __slots__ = ("k", "vec", "first", "s", "p")
 
 
-def hqr2_eigvals(hin, shifts="e44", stats=None):
+def hqr2_eigvals(hin, shifts="e44", stats=None, nb=2):
     h = np.array(hin, dtype=np.float64)
     n = h.shape[0]
     wr = np.zeros(n)
@@ -211,11 +211,12 @@ def hqr2_eigvals(hin, shifts="e44", stats=None):
             if stats is not None and single:
                 stats["single_sweeps"] = stats.get("single_sweeps", 0) + 1
             bl = []
-            for (s_, p_) in (((sA, pA),) if single else ((sA, pA), (sB, pB))):
+            # nb > 2 (model runs only): further bulges repeat the two shift pairs alternately
+            for (s_, p_) in (((sA, pA),) if single else tuple(((sA, pA), (sB, pB))[q & 1] for q in range(nb))):
                 b = _Bulge()
                 b.s, b.p = s_, p_
                 bl.append(b)
-            nit = (i - 1 - m) + 1 + (0 if single else DIST)
+            nit = (i - 1 - m) + 1 + (0 if single else DIST * (nb - 1))
             for t in range(nit):
                 iters_total += 1
                 act = []
