@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Times the level-3 complex solver on config C5 (768 HiPPO-DPLR 256 x 256 matrices): whole eig call and the QR stage.
+   EGS_LIB_PATH selects the library (tools/build_variant.sh)."""
+import importlib, json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle as O
+ops = importlib.import_module("task-level-insights-from-eigenvalues-across-sequence-models_amd").ops
+n, h = 256, 768
+lam, p, _, _, _ = O.make_dplr_hippo(n)
+ls = np.random.default_rng(256).uniform(np.log(1e-3), np.log(1e-1), h)
+d = lambda z: torch.from_numpy(np.ascontiguousarray(z)).cuda()
+ab = ops.s4_dplr_build(d(np.tile(lam.real, (h, 1))), d(np.tile(lam.imag, (h, 1))), d(np.tile(p, (h, 1))), d(ls))
+
+
+def med(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+w, info = ops.eig_general_batched(ab)
+ref = np.linalg.eigvals(ab[:4].cpu().numpy())
+out = {"lib": os.environ.get("EGS_LIB_PATH", "tree"), "eig_ms": med(lambda: ops.eig_general_batched(ab)),
+       "unconverged": int((info != 0).sum().item()),
+       "dlambda_sample": float(O.max_abs_dlambda(w[:4].cpu().numpy(), ref))}
+print(json.dumps(out))
