@@ -182,7 +182,8 @@ def hqr2_eigvals(hin, shifts="e44", stats=None, nb=2):
                     rr = r1 if abs(r1 - d) <= abs(r2 - d) else r2
                     sA, pA = 2.0 * rr, rr * rr
                 sB, pB = sA, pA
-                if shifts == "e44" and i - l + 1 >= 6:
+                # "e44hi" (model runs): the 4 x 4 shifts only while the window still ends at row 44 or later
+                if (shifts == "e44" or (shifts == "e44hi" and i >= 44)) and i - l + 1 >= 6:
                     blk = h[i - 3:i + 1, i - 3:i + 1]
                     sc = float(np.abs(blk).sum())
                     if sc > 0.0:

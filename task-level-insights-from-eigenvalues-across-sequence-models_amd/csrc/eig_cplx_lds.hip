@@ -78,10 +78,9 @@ __global__ __launch_bounds__(kZH) void zhess64_kernel(const double* __restrict__
         int e = 0;
         if (amax > 0.0 && (amax < 1e-100 || amax > 1e100)) e = ilogb(amax);
         if (e != 0) {
-            const double sc = scalbn(1.0, -e);
             for (int idx = tid; idx < n * n; idx += kZH) {
                 zq& v = H[(idx / n) * ldh + (idx % n)];
-                v = {v.re * sc, v.im * sc};
+                v = {scalbn(v.re, -e), scalbn(v.im, -e)};      // (2^-e itself overflows for denormal input)
             }
             __syncthreads();
         }

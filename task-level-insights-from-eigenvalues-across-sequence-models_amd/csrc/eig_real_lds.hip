@@ -103,9 +103,9 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
         if (__ballot(!finite) != 0ULL) e = kNonFinite;           // NaN / Inf input: the QR stage reports failure
         else if (amax > 0.0 && (amax < 1e-100 || amax > 1e100)) e = ilogb(amax);
         if (e != 0 && e != kNonFinite) {
-            const double sc = scalbn(1.0, -e);
+            // (scalbn per entry, not a multiplication by 2^-e: for denormal input 2^-e itself is out of range)
             for (int i = 0; i < n; ++i)
-                if (inr) s[i * kHessLd + lane] *= sc;
+                if (inr) s[i * kHessLd + lane] = scalbn(s[i * kHessLd + lane], -e);
             wave_lds_sync();
         }
         if (lane == 0) scale_exp[mat] = e;

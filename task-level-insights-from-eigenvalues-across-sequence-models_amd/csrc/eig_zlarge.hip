@@ -108,10 +108,9 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
         // negligible absolutely instead of chasing blocks down to the underflow threshold
         if (amax > 0.0) e = ilogb(amax);
         if (e != 0) {
-            const double sc = scalbn(1.0, -e);
             for (int idx = tid; idx < n * n; idx += kZL) {
                 const zq v = M[idx];
-                M[idx] = {v.re * sc, v.im * sc};
+                M[idx] = {scalbn(v.re, -e), scalbn(v.im, -e)};   // (2^-e itself overflows for denormal input)
             }
         }
         if (tid == 0) w[mat * 2 * (int64_t)n] = (double)e;
@@ -1020,7 +1019,11 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
 #define HG(r, c) H[(int64_t)(c) * n + (r)]
     const double ulp = 2.220446049250313e-16;
     const double safmin = 2.2250738585072014e-308;
-    const double smlnum = 1e-200;                // absolute: the Hessenberg stage scaled the matrix to max |entry| in [1, 2)
+    // absolute: the Hessenberg stage scaled the matrix to max |entry| in [1, 2) and leaves columns whose norm is below
+    // 2^-400 (4e-121) unreduced (their squares underflow): everything down there is negligible and has to deflate at once,
+    // or the iteration grinds on blocks that are not even Hessenberg (c ones(n, n), n >= 160: hundreds of sweeps, one
+    // matrix in ten flagged as not converged).  1e-100 of the largest entry is 84 orders below the rounding level.
+    const double smlnum = 1e-100;
     (void)safmin;
     int info = 0;
     int i = n - 1;

@@ -289,11 +289,12 @@ __device__ __forceinline__ int hess_reg_reduce(double (&A)[16][4], const RegLane
         else if (amax > 0.0) e = ilogb(amax);
     }
     {
-        const double sc = (e != 0 && e != kRegNonFinite) ? scalbn(1.0, -e) : 1.0;
+        // (scalbn per entry, not a multiplication by 2^-e: for denormal input 2^-e itself is out of range)
+        const int me = (e != kRegNonFinite) ? -e : 0;
 #pragma unroll
         for (int R = 0; R < 16; ++R)
 #pragma unroll
-            for (int C = 0; C < 4; ++C) A[R][C] *= sc;
+            for (int C = 0; C < 4; ++C) A[R][C] = scalbn(A[R][C], me);
     }
     if (e == kRegNonFinite) balance = 0;            // nothing sensible to balance; the QR stage reports failure
     // ---- xGEBAL: permutation of isolated eigenvalues (rare), then power-of-two scaling of the remaining block ----

@@ -1,0 +1,12 @@
+import importlib, sys, numpy as np, torch
+sys.path.insert(0,'/root/repo')
+ops = importlib.import_module("task-level-insights-from-eigenvalues-across-sequence-models_amd").ops
+g = torch.Generator(device="cuda"); g.manual_seed(11)
+for n in (130, 160, 200, 256, 300):
+    for cplx in (True, False):
+        c = 0.5 + torch.rand((64,1,1), generator=g, device="cuda", dtype=torch.float64)
+        a = torch.ones((64,n,n), device="cuda", dtype=torch.float64)*c
+        if cplx: a = torch.complex(a, torch.zeros_like(a))
+        w, info = ops.eig_general_batched(a.contiguous())
+        bad = (info!=0).nonzero().flatten().cpu().numpy()
+        print(n, cplx, 'bad', bad, info[bad].cpu().numpy() if len(bad) else '', c.flatten()[bad].cpu().numpy() if len(bad) else '', flush=True)

@@ -1,0 +1,10 @@
+import importlib, sys, numpy as np, torch
+sys.path.insert(0,'/root/repo')
+ops = importlib.import_module("task-level-insights-from-eigenvalues-across-sequence-models_amd").ops
+rng=np.random.default_rng(0)
+for n in (5,64,96):
+    for sc in (1e-300, 1e-307, 1e-309, 1e-310):
+        a=rng.standard_normal((4,n,n))*sc
+        w,info=ops.eig_general_batched(torch.from_numpy(a).cuda())
+        ref=np.linalg.eigvals(a)
+        print(n, sc, info.cpu().numpy(), w[0,:2].cpu().numpy(), np.sort_complex(ref[0])[:2], flush=True)
