@@ -335,3 +335,21 @@ def test_denormal_and_near_overflow_input(gpu_ops, n, cplx):
         got = np.ldexp(wr.real, -k) + 1j * np.ldexp(wr.imag, -k)
         # the eigenvalues themselves are denormal for k = -1040: they carry ~30 bits
         assert O.max_abs_dlambda(got, np.linalg.eigvals(back)) < (1e-8 if k < 0 else 1e-11)
+
+@pytest.mark.parametrize("n,cplx", [(1, False), (2, True), (7, True), (33, False), (64, False), (64, True), (65, False), (100, True)])
+def test_non_finite_input_is_flagged_on_every_path(gpu_ops, n, cplx):
+    """Like numpy.linalg.eigvals, NaN / Inf input is an error, not a spectrum: info = n and NaN eigenvalues for that matrix,
+    on every solver path, and its neighbours in the batch are solved as if it were not there."""
+    rng = np.random.default_rng(1800 + n)
+    a = rng.standard_normal((9, n, n)) / np.sqrt(n)
+    if cplx:
+        a = a + 1j * rng.standard_normal((9, n, n)) / np.sqrt(n)
+    b = a.copy()
+    b[2, n // 2, 0] = np.nan
+    b[5, 0, n - 1] = np.inf
+    b[7, n - 1, n - 1] = complex(0, np.inf) if cplx else -np.inf
+    w, info = gpu_ops.eig_general_batched(dev(b))
+    w, info = w.cpu().numpy(), info.cpu().numpy()
+    bad, good = [2, 5, 7], [0, 1, 3, 4, 6, 8]
+    assert (info[bad] == n).all() and (info[good] == 0).all() and np.isnan(w[bad].real).all()
+    assert O.max_abs_dlambda(w[good], np.linalg.eigvals(a[good])) < 1e-11

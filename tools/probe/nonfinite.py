@@ -1,0 +1,21 @@
+import importlib, sys, numpy as np, torch
+sys.path.insert(0,'/root/repo')
+ops = importlib.import_module("task-level-insights-from-eigenvalues-across-sequence-models_amd").ops
+rng=np.random.default_rng(3)
+ok=True
+for n,cplx in ((1,False),(1,True),(2,False),(7,True),(33,False),(64,False),(64,True),(65,False),(100,True),(130,False)):
+    a=rng.standard_normal((9,n,n))/np.sqrt(n)
+    if cplx: a=a+1j*rng.standard_normal((9,n,n))/np.sqrt(n)
+    b=a.copy()
+    b[2,n//2,0]=np.nan; b[5,0,n-1]=np.inf
+    if cplx: b[7,n-1,n-1]=complex(0,np.inf)
+    else: b[7,n-1,n-1]=-np.inf
+    w,info=ops.eig_general_batched(torch.from_numpy(b).cuda())
+    w=w.cpu().numpy(); info=info.cpu().numpy()
+    bad=[2,5,7]; good=[0,1,3,4,6,8]
+    ref=np.linalg.eigvals(a[good])
+    d=max(np.max(np.min(np.abs(ref[k][:,None]-w[g][None,:]),axis=1)) for k,g in enumerate(good))
+    flag = (info[bad]!=0).all() and (info[good]==0).all() and np.isnan(w[bad].real).all() and d<1e-10
+    ok&=bool(flag)
+    print(n,cplx,'info',info,'good dlambda %.1e'%d,'OK' if flag else '<<<<< CHECK',flush=True)
+print('ALL OK' if ok else 'FAILURES')
