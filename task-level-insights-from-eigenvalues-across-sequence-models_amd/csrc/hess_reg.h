@@ -289,12 +289,21 @@ __device__ __forceinline__ int hess_reg_reduce(double (&A)[16][4], const RegLane
         else if (amax > 0.0) e = ilogb(amax);
     }
     {
-        // (scalbn per entry, not a multiplication by 2^-e: for denormal input 2^-e itself is out of range)
+        // two exact factors: for denormal input (e < -1023) 2^-e itself is out of range
         const int me = (e != kRegNonFinite) ? -e : 0;
+        const int m1 = me > 1000 ? 1000 : me;
+        const double sc = scalbn(1.0, m1);
 #pragma unroll
         for (int R = 0; R < 16; ++R)
 #pragma unroll
-            for (int C = 0; C < 4; ++C) A[R][C] = scalbn(A[R][C], me);
+            for (int C = 0; C < 4; ++C) A[R][C] *= sc;
+        if (__builtin_expect(me > 1000, 0)) {              // wave-uniform, denormal input only
+            const double sc2 = scalbn(1.0, me - 1000);
+#pragma unroll
+            for (int R = 0; R < 16; ++R)
+#pragma unroll
+                for (int C = 0; C < 4; ++C) A[R][C] *= sc2;
+        }
     }
     if (e == kRegNonFinite) balance = 0;            // nothing sensible to balance; the QR stage reports failure
     // ---- xGEBAL: permutation of isolated eigenvalues (rare), then power-of-two scaling of the remaining block ----
