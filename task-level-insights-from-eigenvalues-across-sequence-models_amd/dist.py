@@ -73,6 +73,49 @@ def all_gather_slabs(local, n_total, group=None):
     return out[:n_total].to(device)
 
 
+class _GatherHandle:
+    """Result of all_gather_slabs_async: wait() makes the current stream wait for the collective and returns the full
+    tensor.  Holds the input slab and the output until then (the collective reads / writes them on RCCL's stream)."""
+
+    def __init__(self, out, n_total, device, work=None, keep=None):
+        self._out, self._n, self._device, self._work, self._keep = out, n_total, device, work, keep
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._keep = None
+        return self._out[:self._n].to(self._device)
+
+
+def all_gather_slabs_async(local, n_total, group=None):
+    """all_gather_slabs without blocking the launch stream: on RCCL the collective runs on its own stream (after the work
+    already queued on the current one) and the caller goes on to launch the next batch's kernels; .wait() joins.  With
+    host-staged (gloo) groups the exchange is done at once and the handle is already complete."""
+    rank, world_size = world()
+    if world_size == 1:
+        return _GatherHandle(local, local.shape[0], local.device)
+    if local.is_cuda and _host_staged(group):
+        return _GatherHandle(all_gather_slabs(local, n_total, group), n_total, local.device)
+    return _gather_async(local, n_total, world_size, group)
+
+
+def _gather_async(local, n_total, world_size, group=None):
+    """The collective itself (separate so that a one-rank RCCL group can exercise it on a one-GPU box)."""
+    per = (n_total + world_size - 1) // world_size
+    pad = per - local.shape[0]
+    if pad > 0:
+        filler = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, filler], dim=0)
+    local = local.contiguous()
+    out = torch.empty((world_size * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if local.is_complex():
+        work = dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(local), group=group, async_op=True)
+    else:
+        work = dist.all_gather_into_tensor(out, local, group=group, async_op=True)
+    return _GatherHandle(out, n_total, local.device, work, local)
+
+
 def all_reduce_slab_sum(full, group=None):
     """The histogram-only exchange of SURVEY.md 8(e): every rank has filled ITS batch rows of `full` (zeros elsewhere),
     one all_reduce(sum) completes it on every rank.  Bit-exact: each element receives exactly one non-zero term."""

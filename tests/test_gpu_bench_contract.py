@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_bench_line_schema_and_consistency():
     nmat = 16384
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
@@ -56,3 +63,37 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["world"] == 2 and d["dist_backend"] == "gloo" and d["scaling"] == "weak"
     assert d["unconverged"] == 0 and d["max_abs_dlambda_vs_lapack"] < 1e-5
     assert abs(d["value"] - 2 * nmat / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_pipelined_all_gather_on_a_one_rank_rccl_group(tmp_path):
+    """bench.py overlaps the RCCL all-gather of step k with the kernels of step k + 1 (dist.all_gather_slabs_async).
+    Two ranks cannot share this box's one GPU under RCCL, so the collective itself is exercised on a ONE-rank RCCL
+    group in a fresh process: two gathers in flight beside solver launches, results equal to the slabs, nothing
+    freed or overwritten early."""
+    code = r'''
+import importlib, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+pkg = importlib.import_module("task-level-insights-from-eigenvalues-across-sequence-models_amd")
+g = torch.Generator(device="cuda"); g.manual_seed(5)
+a = torch.randn((4096, 64, 64), generator=g, device="cuda", dtype=torch.float64) / 8
+w_ref, _ = pkg.ops.eig_general_batched(a)
+pending, outs = None, []
+for k in range(3):
+    w, info = pkg.ops.eig_general_batched(a * 2.0 ** k)              # power of two: the spectrum scales exactly
+    h = pkg.dist._gather_async(w, w.shape[0], 1)
+    if pending is not None:
+        outs.append(pending.wait())
+    pending = h
+outs.append(pending.wait())
+torch.cuda.synchronize()
+ok = all(torch.equal(torch.view_as_real(o), torch.view_as_real(w_ref * 2.0 ** k)) for k, o in enumerate(outs))
+dist.destroy_process_group()
+print("RCCL-ONE-RANK", "ok" if ok else "mismatch")
+''' % (ROOT, _free_port())
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "EGS_DIST_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "RCCL-ONE-RANK ok" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])

@@ -107,6 +107,10 @@ def _gather_worker(rank, world, port, n_total, out_dir):
     got_real = egs_dist.all_gather_slabs(full[lo:hi].clone(), n_total)
     got_cplx = egs_dist.all_gather_slabs(cfull[lo:hi].clone(), n_total)
     ok = torch.equal(got_real, full) and torch.equal(got_cplx, cfull)
+    # the non-blocking form bench.py pipelines (collective of step k beside the kernels of step k + 1): two in flight
+    h1 = egs_dist.all_gather_slabs_async(cfull[lo:hi].clone(), n_total)
+    h2 = egs_dist.all_gather_slabs_async((2 * full[lo:hi]).clone(), n_total)
+    ok = ok and torch.equal(h1.wait(), cfull) and torch.equal(h2.wait(), 2 * full)
     open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
     dist.destroy_process_group()
 
