@@ -703,29 +703,36 @@ __device__ __forceinline__ void lds_read3x2(const double* p, const double* q, do
 }
 
 // Predicated store of three doubles p[0], p[S1], p[2 S1] by the lanes with e <= thr (GE: e >= thr; thr wave-uniform): v_cmpx writes
-// EXEC directly, the stores run under it, EXEC goes back to all ones -- two instructions of overhead instead of the
+// EXEC directly, the stores run under it, EXEC goes back to `full` -- two instructions of overhead instead of the
 // compare + s_and_saveexec + s_cbranch_execz + s_or the compiler emits for `if (e <= thr) { ... }`, and no branch.
-// Only used where control flow is wave-uniform with all 64 lanes alive (the steady-state iterations of a sweep).
+// `full` is the EXEC mask the enclosing steady-state loop was ENTERED with (read once in front of the loop, qr2_segment:
+// no instruction per iteration), so the statement stays correct if a compiler ever runs that loop under a predicate;
+// tests/test_isa_invariants.py checks on the emitted code that nothing else inside such a loop writes EXEC.
+// (Saving and restoring EXEC inside the statement measured 0.9 % of the C2 step, `s_mov_b64 exec, -1` assumed all 64
+// lanes live without telling anybody.)
 template <int S1, bool GE>
-__device__ __forceinline__ void lds_store3_where(int e, int thr, double* p, double v0, double v1, double v2) {
+__device__ __forceinline__ void lds_store3_where(int e, int thr, double* p, double v0, double v1, double v2,
+                                                 unsigned long long full) {
     static_assert(2 * S1 < 256, "ds_write2_b64 offsets are 8-bit, in units of 8 bytes");
     if (GE)
         asm volatile(
-            "v_cmpx_le_i32_e32 vcc, %1, %0\n\t"
-            "ds_write2_b64 %2, %3, %4 offset1:%6\n\t"
-            "ds_write_b64 %2, %5 offset:%7\n\t"
-            "s_mov_b64 exec, -1"
+            "v_cmpx_le_i32_e32 vcc, %[thr], %[e]\n\t"
+            "ds_write2_b64 %[p], %[v0], %[v1] offset1:%[o1]\n\t"
+            "ds_write_b64 %[p], %[v2] offset:%[o2]\n\t"
+            "s_mov_b64 exec, %[full]"
             :
-            : "v"(e), "s"(thr), "v"((unsigned)(uintptr_t)p), "v"(v0), "v"(v1), "v"(v2), "n"(S1), "n"(2 * S1 * 8)
+            : [e] "v"(e), [thr] "s"(thr), [p] "v"((unsigned)(uintptr_t)p), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2),
+              [o1] "n"(S1), [o2] "n"(2 * S1 * 8), [full] "s"(full)
             : "vcc", "memory");
     else
         asm volatile(
-            "v_cmpx_ge_i32_e32 vcc, %1, %0\n\t"
-            "ds_write2_b64 %2, %3, %4 offset1:%6\n\t"
-            "ds_write_b64 %2, %5 offset:%7\n\t"
-            "s_mov_b64 exec, -1"
+            "v_cmpx_ge_i32_e32 vcc, %[thr], %[e]\n\t"
+            "ds_write2_b64 %[p], %[v0], %[v1] offset1:%[o1]\n\t"
+            "ds_write_b64 %[p], %[v2] offset:%[o2]\n\t"
+            "s_mov_b64 exec, %[full]"
             :
-            : "v"(e), "s"(thr), "v"((unsigned)(uintptr_t)p), "v"(v0), "v"(v1), "v"(v2), "n"(S1), "n"(2 * S1 * 8)
+            : [e] "v"(e), [thr] "s"(thr), [p] "v"((unsigned)(uintptr_t)p), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2),
+              [o1] "n"(S1), [o2] "n"(2 * S1 * 8), [full] "s"(full)
             : "vcc", "memory");
 }
 
@@ -754,7 +761,8 @@ struct Qr2Lane {
 // store block: five serialised round trips per iteration.)  The empty asm statements pin the batches.
 template <bool GEN, bool R2, bool C2, class V>
 __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int t, const bool first, const bool last,
-                                         const bool top, const double v0, const double v1, const double v2) {
+                                         const bool top, const double v0, const double v1, const double v2,
+                                         const unsigned long long full = ~0ULL) {
     constexpr int SR = V::kSR, SC = V::kSC;
     double a0, a1, a2, x0, x1, x2;
     double* const rp2 = S.rowp + S.d_r;
@@ -803,7 +811,7 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int t, const bool fir
         const double sum = fma(u2, x2, fma(u1, x1, x0));
         const double n0 = fma(-sum, t1, x0), n1 = fma(-sum, t2, x1), n2 = fma(-sum, t3, x2);
         if (!GEN) {
-            lds_store3_where<SR, true>(S.er0, t, S.rowp, n0, n1, n2);
+            lds_store3_where<SR, true>(S.er0, t, S.rowp, n0, n1, n2, full);
         } else if (S.er0 >= tg) {
             S.rowp[0] = n0;
             S.rowp[SR] = n1;
@@ -814,7 +822,7 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int t, const bool fir
         const double sum = fma(u2, y2, fma(u1, y1, y0));
         const double n0 = fma(-sum, t1, y0), n1 = fma(-sum, t2, y1), n2 = fma(-sum, t3, y2);
         if (!GEN) {
-            lds_store3_where<SR, true>(S.er1, t, rp2, n0, n1, n2);
+            lds_store3_where<SR, true>(S.er1, t, rp2, n0, n1, n2, full);
         } else if (S.er1 >= tg) {
             rp2[0] = n0;
             rp2[SR] = n1;
@@ -847,7 +855,7 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int t, const bool fir
         const double sum = fma(u2, c2, fma(u1, c1, c0));
         const double n0 = fma(-sum, t1, c0), n1 = fma(-sum, t2, c1), n2 = fma(-sum, t3, c2);
         if (!GEN) {
-            lds_store3_where<SC, false>(S.ec0, t, S.colp, n0, n1, n2);
+            lds_store3_where<SC, false>(S.ec0, t, S.colp, n0, n1, n2, full);
         } else if (S.ec0 <= t) {
             S.colp[0] = n0;
             S.colp[SC] = n1;
@@ -858,7 +866,7 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int t, const bool fir
         const double sum = fma(u2, d2, fma(u1, d1, d0));
         const double n0 = fma(-sum, t1, d0), n1 = fma(-sum, t2, d1), n2 = fma(-sum, t3, d2);
         if (!GEN) {
-            lds_store3_where<SC, false>(S.ec1, t, cp2, n0, n1, n2);
+            lds_store3_where<SC, false>(S.ec1, t, cp2, n0, n1, n2, full);
         } else if (S.ec1 <= t) {
             cp2[0] = n0;
             cp2[SC] = n1;
@@ -874,7 +882,8 @@ __device__ __forceinline__ void qr2_iter(Qr2Lane& S, const int t, const bool fir
 // steady-state iterations t0 <= t < t1 of one (R2, C2) segment
 template <bool R2, bool C2, class V>
 __device__ __forceinline__ void qr2_segment(Qr2Lane& S, int t0, const int t1) {
-    for (int t = t0; t < t1; ++t) qr2_iter<false, R2, C2, V>(S, t, false, false, false, 0.0, 0.0, 0.0);
+    const unsigned long long full = __builtin_amdgcn_read_exec();    // the lanes this loop runs with (lds_store3_where)
+    for (int t = t0; t < t1; ++t) qr2_iter<false, R2, C2, V>(S, t, false, false, false, 0.0, 0.0, 0.0, full);
 }
 
 // One sweep over the window [l, i] from start row m with start vector (v0, v1, v2); (rt1r, rt1i, rt2r, rt2i) are the
@@ -1335,10 +1344,12 @@ __host__ __device__ inline int hqr_pair_ld(int n) {
 
 template <class V>
 __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ src, int n, int lane,
-                                        double* __restrict__ wo, int32_t* __restrict__ info, double rescale) {
+                                        double* __restrict__ wo, int32_t* __restrict__ info, double rescale,
+                                        const bool normalise) {
     // load the Hessenberg part plus the two extra sub-diagonals a bulge may touch (zeros); 8 rows of global loads in
     // flight at a time, always from valid addresses (clamped lane), zeroed / dropped by value afterwards
     const int lcl = (lane < n) ? lane : n - 1;
+    double amax = 0.0;
     int i = 0;
     for (; i + 8 <= n; i += 8) {
         double t[8];
@@ -1346,13 +1357,37 @@ __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ sr
         for (int u = 0; u < 8; ++u) t[u] = src[(int64_t)(i + u) * n + lcl];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (lane < n && i + u <= lane + 3) H.at(i + u, lane) = (i + u <= lane + 1) ? t[u] : 0.0;
+            if (lane < n && i + u <= lane + 3) {
+                const double v = (i + u <= lane + 1) ? t[u] : 0.0;
+                H.at(i + u, lane) = v;
+                amax = fmax(amax, fabs(v));
+            }
     }
     for (; i < n; ++i) {
         const double t = src[(int64_t)i * n + lcl];
-        if (lane < n && i <= lane + 3) H.at(i, lane) = (i <= lane + 1) ? t : 0.0;
+        if (lane < n && i <= lane + 3) {
+            const double v = (i <= lane + 1) ? t : 0.0;
+            H.at(i, lane) = v;
+            amax = fmax(amax, fabs(v));
+        }
     }
     wave_lds_sync();
+    if (normalise) {
+        // The n = 64 layouts deflate and guard with ABSOLUTE thresholds that assume max |entry| in [1, 2) (the eigenvalue
+        // driver's Hessenberg stage scales so).  A Hessenberg matrix handed in through egs_hseqr_batched comes as the
+        // caller made it: scale it here by a power of two (exact) and multiply the eigenvalues back.
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
+        if (amax > 0.0 && amax <= 1.7976931348623157e308) {
+            const int e = ilogb(amax);
+            if (e != 0) {
+                for (int r = 0; r < n; ++r)
+                    if (lane < n && r <= lane + 1) H.at(r, lane) = scalbn(H.at(r, lane), -e);
+                wave_lds_sync();
+                rescale = scalbn(rescale, e);
+            }
+        }
+    }
     hqr_wave(H, n, lane, wo, info, rescale);
 }
 
@@ -1391,11 +1426,11 @@ __global__ __launch_bounds__(512, EGS_HQR_MIN_WAVES_PER_EU) void hqr_real_kernel
         } else {
         const double rescale = scaled ? scalbn(1.0, info[mat]) : 1.0;
         if constexpr (N64) {
-            if ((wave & 1) == 0) hqr_run(MatViewT<kLd64, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
-            else hqr_run(MatViewT<kLd64, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
+            if ((wave & 1) == 0) hqr_run(MatViewT<kLd64, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale, !scaled);
+            else hqr_run(MatViewT<kLd64, true>{base, ldp}, src, n, lane, wo, info + mat, rescale, !scaled);
         } else {
-            if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale);
-            else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat, rescale);
+            if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale, false);
+            else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat, rescale, false);
         }
         }
         wave_lds_sync();                                          // this matrix's LDS traffic is complete before the next load

@@ -913,6 +913,212 @@ __device__ __forceinline__ void zchase3_steady(zq* __restrict__ Wn, zq* __restri
 #undef SSTAMP
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the chase with every wave computing its OWN next rotation.
+//
+// zchase3 gave the rotation of step t+1 to four "look-ahead" waves (four bulges each, one lane per bulge), fed through
+// a mailbox and a parameter table in LDS.  That put the ~150-instruction scalar chain on 4 lanes of 4 waves and cost every
+// wave and step three parameter reads and one mailbox store, the look-ahead waves five reads and four stores more: 32 of
+// the 112 ds_write_b128 of a chain step (13 LDS cycles each -- the resource the step is bound by, profiles/r03_c5_*).
+// But the two numbers the next rotation is computed from are RESULTS OF THE WAVE'S OWN COLUMN OPERATION: with the bulge
+// at window row pw, the column operation on columns pw, pw+1 (lane = row) leaves the new H(pw+1, pw) in lane pw+1 and the
+// new bulge H(pw+2, pw) in lane pw+2 of its first result.  Two lane broadcasts (8 v_readlane_b32) and a rotation computed
+// on wave-uniform values replace mailbox, table and look-ahead lanes: no cross-wave traffic besides the window itself,
+// 5 LDS reads + 5 stores per wave and step instead of 8-13 + 6-10, all waves symmetric (no priority games).  The rotation
+// is computed at the START of the next row phase, behind the row loads: a phase begins with all 16 waves queueing on the
+// LDS pipe, so every wave has a few hundred cycles of load latency to fill.
+// The arithmetic is that of zchase3 / zchase3_steady, element for element.
+// ---------------------------------------------------------------------------------------------------
+
+// zgivens on WAVE-UNIFORM operands.  Fast path (one reciprocal square root): with d = 1 / sqrt(|a0|^2 (|a0|^2 + |a1|^2)),
+//     c = |a0|^2 d,   s = a0 conj(a1) d,   rho = a0 (|a0|^2 + |a1|^2) d;
+// operands whose squares leave the safe range take zgivens (uniform branch, rare: sub-diagonal entries below 1e-70 of a
+// matrix scaled to max |entry| in [1, 2)).
+template <bool RHO>
+__device__ __forceinline__ void zgivens_u(zq a0, zq a1, double& c, zq& sn, zq& rho) {
+    const double n0 = fma(a0.re, a0.re, a0.im * a0.im);
+    const double n1 = fma(a1.re, a1.re, a1.im * a1.im);
+    const double nn = n0 + n1;
+    if (n0 >= 1e-140 && nn <= 1e140) {                                  // uniform
+        const double d = fast_rsqrt(n0 * nn);
+        c = n0 * d;
+        const zq t = qmulc(a0, a1);
+        sn = {t.re * d, t.im * d};
+        if (RHO) {
+            const double g = nn * d;
+            rho = {a0.re * g, a0.im * g};
+        }
+    } else {
+        zgivens(a0, a1, c, sn, rho);
+    }
+}
+
+__device__ __forceinline__ zq qbcast_u(zq x, int src) {                 // src wave-uniform
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    return {__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x.re), s),
+                             __builtin_amdgcn_readlane(__double2loint(x.re), s)),
+            __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x.im), s),
+                             __builtin_amdgcn_readlane(__double2loint(x.im), s))};
+}
+
+// General body: bulges being introduced, leaving the active block, clipped windows.  Same window protocol as zchase3:
+// phase 1 = rows p, p+1 of the window (lane = column), phase 2 = columns p, p+1 of the window and of U (lane = row).
+template <bool WITHU>
+__device__ __forceinline__ void zchase4(zq* __restrict__ Wn, zq* __restrict__ Un, const zq* __restrict__ shifts, int s,
+                                        int wd, int l, int i, int t0, int t1, int lane, int wv, const bool prof,
+                                        long long (&cst)[4]) {
+    long long tl = prof ? (long long)__builtin_readcyclecounter() : 0;
+#define CSTAMP(k)                                                  \
+    if (prof) {                                                    \
+        const long long now_ = __builtin_readcyclecounter();       \
+        cst[k] += now_ - tl;                                       \
+        tl = now_;                                                 \
+    }
+    const int b = wv;
+    double c = 1.0;
+    zq sn = {0.0, 0.0}, rho = {0.0, 0.0};
+    zq a0n = {0.0, 0.0}, a1n = {0.0, 0.0};                             // pair the coming step's rotation annihilates
+    bool have = false;                                                 // (a0n, a1n) valid
+    zq ucar = {0.0, 0.0};
+    bool ucv = false;                                                  // ucar holds column p of U
+    for (int t = t0; t <= t1; ++t) {
+        const int tb = t - 2 * b;
+        const int p = l + tb;
+        const bool act = tb >= 0 && p <= i - 1;                        // wave-uniform
+        const int pw = p - s;
+        // ---- phase 1: rows p, p+1 of the window (lane = column) ----
+        if (act) {
+            const zq r0 = Wn[pw * QLD + lane], r1 = Wn[(pw + 1) * QLD + lane];   // in flight under the rotation
+            if (!have) {
+                // first step of the stage (pair in column p-1 of the bulge's own rows: nobody else writes them in this
+                // phase) or introduction of the bulge (first column of H - shift I)
+                const bool intro = tb == 0;
+                const int pc = intro ? pw : pw - 1;
+                a0n = Wn[pw * QLD + pc];
+                a1n = Wn[(pw + 1) * QLD + pc];
+                if (intro) a0n = qsub(a0n, shifts[b]);
+            }
+            zgivens_u<true>(a0n, a1n, c, sn, rho);
+            zq y0, y1;
+            zrot_rows(c, sn, r0, r1, y0, y1);
+            // column p-1 holds the bulge this rotation annihilates: lane p-1 stores (rho, 0) with the same two stores
+            const bool bl_lane = tb >= 1 && lane == pw - 1;
+            if ((lane >= pw && lane < wd) || bl_lane) {
+                Wn[pw * QLD + lane] = qsel(bl_lane, rho, y0);
+                Wn[(pw + 1) * QLD + lane] = qsel(bl_lane, zq{0.0, 0.0}, y1);
+            }
+        }
+        CSTAMP(0)
+        __syncthreads();
+        CSTAMP(1)
+        // ---- phase 2: columns p, p+1 of the window and of U (lane = row); the pair of the wave's next rotation ----
+        have = false;
+        if (act) {
+            const int rmaxw = ((p + 2 < i) ? p + 2 : i) - s;
+            const zq c0 = Wn[lane * QLD + pw], c1 = Wn[lane * QLD + pw + 1];
+            zq ul = {0.0, 0.0}, u1 = {0.0, 0.0};
+            if (WITHU) {
+                if (!ucv) ul = Un[lane * QLD + pw];
+                u1 = Un[lane * QLD + pw + 1];
+            }
+            zq y0, y1;
+            zrot_cols(c, sn, c0, c1, y0, y1);
+            if (lane <= rmaxw) {
+                Wn[lane * QLD + pw] = y0;
+                Wn[lane * QLD + pw + 1] = y1;
+            }
+            const bool more = t < t1 && p + 1 <= i - 1;                // the bulge moves on inside this window
+            if (more) {
+                // new H(p+1, p) and the new bulge H(p+2, p): lanes pw+1, pw+2 of the first result column
+                a0n = qbcast_u(y0, pw + 1);
+                a1n = qbcast_u(y0, pw + 2);
+                have = true;
+            }
+            if (WITHU) {
+                // column p of U is still in this wave's registers from the previous step (no other bulge touches it)
+                const zq u0 = qsel(ucv, ucar, ul);
+                zq v0, v1;
+                zrot_cols(c, sn, u0, u1, v0, v1);
+                ucv = more;
+                ucar = v1;
+                if (lane < wd) {
+                    Un[lane * QLD + pw] = v0;
+                    if (!more) Un[lane * QLD + pw + 1] = v1;
+                }
+            }
+        }
+        CSTAMP(2)
+        __syncthreads();
+        CSTAMP(3)
+    }
+#undef CSTAMP
+}
+
+// Interior stages (conditions and constants of zchase3_steady): every flag of the general body is a constant.
+template <bool PROF>
+__device__ __forceinline__ void zchase4_steady(zq* __restrict__ Wn, zq* __restrict__ Un, int t0, int t1, int lane, int wv,
+                                               long long (&cst)[4]) {
+    long long tl = PROF ? (long long)__builtin_readcyclecounter() : 0;
+#define SSTAMP(k)                                                  \
+    if (PROF) {                                                    \
+        const long long now_ = __builtin_readcyclecounter();       \
+        cst[k] += now_ - tl;                                       \
+        tl = now_;                                                 \
+    }
+    constexpr int P0 = 2 * (QM - 1) + 1;                               // window row of bulge 0 at step t0
+    int pw = P0 - 2 * wv;
+    zq* rowp = Wn + pw * QLD + lane;                                   // (pw, lane), advances by QLD
+    zq* colp = Wn + lane * QLD + pw;                                   // (lane, pw), advances by 1
+    zq* ucol = Un + lane * QLD + pw;
+    zq a0n = Wn[pw * QLD + pw - 1], a1n = Wn[(pw + 1) * QLD + pw - 1];   // own rows: no barrier needed
+    zq ucar = ucol[0];                                                 // column pw of U: carried from step to step
+    for (int t = t0; t <= t1; ++t) {
+        double c;
+        zq sn, rho;
+        // ---- phase 1: rows pw, pw+1 of the window (lane = column); column pw-1 goes through the rotation too ----
+        {
+            const zq r0 = rowp[0], r1 = rowp[QLD];                      // in flight while the rotation is computed
+            zgivens_u<false>(a0n, a1n, c, sn, rho);
+            zq y0, y1;
+            zrot_rows(c, sn, r0, r1, y0, y1);
+            if (lane >= pw - 1) {
+                rowp[0] = y0;
+                rowp[QLD] = y1;
+            }
+        }
+        SSTAMP(0)
+        __syncthreads();
+        SSTAMP(1)
+        // ---- phase 2: columns pw, pw+1 of the window and of U (lane = row); pair of the next rotation ----
+        {
+            const zq c0 = colp[0], c1 = colp[1];
+            const zq u1 = ucol[1];
+            zq y0c, y1c;
+            zrot_cols(c, sn, c0, c1, y0c, y1c);
+            if (lane <= pw + 2) {
+                colp[0] = y0c;
+                colp[1] = y1c;
+            }
+            a0n = qbcast_u(y0c, pw + 1);                                // (unused after step t1)
+            a1n = qbcast_u(y0c, pw + 2);
+            zq v0, v1;
+            zrot_cols(c, sn, ucar, u1, v0, v1);
+            ucol[0] = v0;
+            ucar = v1;
+        }
+        SSTAMP(2)
+        __syncthreads();
+        SSTAMP(3)
+        ++pw;
+        rowp += QLD;
+        colp += 1;
+        ucol += 1;
+    }
+    ucol[0] = ucar;                                                    // column pw(t1) + 1 of U
+    __syncthreads();
+#undef SSTAMP
+}
+
 // Deferred update of one side by the accumulated U (both as  out(f, g) = sum_k X(k, f) U'(k, g)  on the matrix cores):
 //   LEFT = false: rows [f0, f0 + nf) above the window:    H(f0 + f, s + g) <- sum_k H(f0 + f, s + k) U(k, g)
 //   LEFT = true : columns [f0, f0 + nf) right of it:      H(s + g, f0 + f) <- sum_k conj(U(k, g)) H(s + k, f0 + f)
@@ -1137,7 +1343,11 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
                 Wn[r * QLD + c] = qsel(ok, HG(l + (r < na ? r : 0), l + (c < na ? c : 0)), zq{0.0, 0.0});
             }
             __syncthreads();
+            #ifdef EGS_ZCHASE_LOOKAHEAD
             zchase3<false>(Wn, Un, prm, mbx, shifts, l, na, l, i, 0, tmax, lane, wv, false, cst);
+#else
+            zchase4<false>(Wn, Un, shifts, l, na, l, i, 0, tmax, lane, wv, false, cst);
+#endif
             for (int e = tid; e < QW * QW; e += kZL) {
                 const int c = e >> 6, r = e & 63;
                 if (r < na && c < na) HG(l + r, l + c) = Wn[r * QLD + c];
@@ -1166,9 +1376,15 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
             if (t0 >= 2 * (QM - 1) + 1 && l + t1 + 3 <= i && wd == QW && !zgeneral_only) {
                 // (EGS_ZCHASE_STAMPS builds stamp this body too: 26.2 against 29.8 Mcycles of chase per C5 matrix,
                 // profiles/r03_c5_phase_cycles.json)
+#ifdef EGS_ZCHASE_LOOKAHEAD
                 zchase3_steady<kZSteadyStamps>(Wn, Un, prm, mbx, t0, t1, lane, wv, cst);
             } else
                 zchase3<true>(Wn, Un, prm, mbx, shifts, s, wd, l, i, t0, t1, lane, wv, prof != nullptr, cst);
+#else
+                zchase4_steady<kZSteadyStamps>(Wn, Un, t0, t1, lane, wv, cst);
+            } else
+                zchase4<true>(Wn, Un, shifts, s, wd, l, i, t0, t1, lane, wv, prof != nullptr, cst);
+#endif
             ZSTAMP(pacc3)
             for (int e = tid; e < QW * QW; e += kZL) {
                 const int c = e >> 6, r = e & 63;

@@ -105,7 +105,7 @@ __device__ __forceinline__ zq qdiv_fast(zq a, zq b) {
 template <class V, bool SHIFTS = false>
 __device__ void zhqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
                           int32_t* __restrict__ info_out, const double rescale = 1.0) {
-    const double ulp = SHIFTS ? 1e-11 : 2.220446049250313e-16;
+    const double ulp = SHIFTS ? 1e-11 : 2.220446049250313e-16;   // (1e-7 / 1e-5 measured in round 4: more sweeps, C5 +2-3 ms)
     const double safmin = 2.2250738585072014e-308;
     const double smlnum = safmin * ((double)n / ulp);
     const int itmax = 30 * (n > 10 ? n : 10);

@@ -91,11 +91,13 @@ class _GatherHandle:
 def all_gather_slabs_async(local, n_total, group=None):
     """all_gather_slabs without blocking the launch stream: on RCCL the collective runs on its own stream (after the work
     already queued on the current one) and the caller goes on to launch the next batch's kernels; .wait() joins.  With
-    host-staged (gloo) groups the exchange is done at once and the handle is already complete."""
+    host-staged (gloo) groups, or with EGS_GATHER_SYNC=1, the exchange is done at once and the handle is already complete."""
     rank, world_size = world()
     if world_size == 1:
         return _GatherHandle(local, local.shape[0], local.device)
-    if local.is_cuda and _host_staged(group):
+    if (local.is_cuda and _host_staged(group)) or os.environ.get("EGS_GATHER_SYNC"):
+        # EGS_GATHER_SYNC=1: the blocking collective as a fallback (the overlapped form has only been rehearsed on a
+        # one-rank RCCL group and on gloo: no multi-GPU node in reach of this build)
         return _GatherHandle(all_gather_slabs(local, n_total, group), n_total, local.device)
     return _gather_async(local, n_total, world_size, group)
 

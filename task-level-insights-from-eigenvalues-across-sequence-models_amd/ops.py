@@ -12,6 +12,7 @@ from . import _capi
 from ._capi import check, lib
 
 _workspaces = {}
+_workspace_caps = {}
 
 
 def _require_cuda(t, name):
@@ -29,20 +30,40 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _workspace(device, nbytes, tag="scratch"):
+def _workspace(device, nbytes, tag="scratch", floor=None):
     """Grow-only scratch buffer per (device, stream, purpose) -- the C ABI never allocates.  Keyed by the CURRENT
     stream: two streams (or two host threads driving their own streams) never share scratch, and a buffer is only ever
-    released to torch's caching allocator from the stream that used it, which keeps the release stream-ordered."""
+    released to torch's caching allocator from the stream that used it, which keeps the release stream-ordered.
+
+    `floor`: the entry point also works with less than `nbytes` (the real n <= 64 eigenvalue solver then runs its batch
+    in several passes, include/eigspec.h): when the device cannot give `nbytes`, the request is halved down to `floor`
+    before the out-of-memory error is passed on, and the size that fitted is remembered for this key."""
     nbytes = max(int(nbytes), 256)
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    cap = _workspace_caps.get(key)
+    if floor is not None and cap is not None:
+        nbytes = max(min(nbytes, cap), int(floor))
     buf = _workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        _workspaces[key] = buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return buf
+    if buf is not None and buf.numel() >= nbytes:
+        return buf
+    _workspaces.pop(key, None)
+    del buf
+    want = nbytes
+    while True:
+        try:
+            _workspaces[key] = buf = torch.empty(want, dtype=torch.uint8, device=device)
+            return buf
+        except torch.cuda.OutOfMemoryError:
+            if floor is None or want <= int(floor):
+                raise
+            torch.cuda.empty_cache()
+            want = max(int(floor), want // 2)
+            _workspace_caps[key] = want
 
 
 def release_workspaces():
     _workspaces.clear()
+    _workspace_caps.clear()
 
 
 def device_props(device=0):
@@ -80,9 +101,17 @@ def eig_general_batched(a, workspace=None):
     dtype = _EIG_DTYPES[a.dtype]
     w = torch.empty((nmat, n), dtype=torch.complex128, device=a.device)
     info = torch.empty((nmat,), dtype=torch.int32, device=a.device)
-    need = lib().egs_eig_workspace_bytes(dtype, nmat, n)
-    ws = workspace if workspace is not None else _workspace(a.device, need)
     with torch.cuda.device(a.device):
+        # query and launch under the SAME current device: the n = 64 sizes depend on its compute-unit count
+        if workspace is not None:
+            ws = workspace
+        else:
+            need = lib().egs_eig_workspace_bytes(dtype, nmat, n)
+            # real float64 input of order <= 64 is solved in passes over whatever the workspace holds (eigspec.h): under
+            # memory pressure take less instead of failing (n = 64 asks for 15.5 KB per matrix of a pass)
+            floor = (lib().egs_eig_workspace_bytes(dtype, min(nmat, 32768), n)
+                     if a.dtype == torch.float64 and n <= 64 else None)
+            ws = _workspace(a.device, need, floor=floor)
         check(lib().egs_eig_general_batched(_ptr(a3), dtype, nmat, n, n, n * n, _ptr(w), _ptr(info), _ptr(ws),
                                             ws.numel() * ws.element_size(), _stream()), "egs_eig_general_batched")
     return w.reshape(*batch_shape, n), info.reshape(batch_shape)

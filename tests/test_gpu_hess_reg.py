@@ -329,3 +329,47 @@ def test_constant_rank_one_and_nilpotent_matrices(gpu_ops):
     nil = torch.triu(torch.randn((64, n, n), generator=g, device="cuda", dtype=torch.float64), 1)
     w, info = gpu_ops.eig_general_batched(nil)
     assert int(info.abs().sum().item()) == 0 and float(w.abs().max().item()) == 0.0   # exact zeros stay exact
+
+
+@pytest.mark.parametrize("scale", [1e-220, 1e-150, 1.0, 1e150, 1e220])
+def test_two_stage_api_on_unscaled_hessenberg_input(gpu_ops, scale):
+    """egs_hessenberg_batched -> egs_hseqr_batched hands the n = 64 QR kernel a matrix nobody scaled: its absolute
+    deflation / tiny-column thresholds assume max |entry| in [1, 2), so the kernel normalises such input itself (entries
+    of 1e-220 used to deflate wholesale: the diagonal came back as the spectrum with info = 0)."""
+    rng = np.random.default_rng(670)
+    a = rng.standard_normal((24, 64, 64)) / 8
+    h = gpu_ops.hessenberg_batched(dev(a * scale))
+    w, info = gpu_ops.hseqr_batched(h)
+    assert int(info.abs().sum().item()) == 0
+    ref = np.linalg.eigvals(a)
+    assert O.max_abs_dlambda(w.cpu().numpy() / scale, ref) < 1e-11
+    # a hand-made Hessenberg matrix (no reduction in front), also through the raw second stage
+    hh = np.triu(rng.standard_normal((8, 64, 64)), -1) * scale
+    w2, info2 = gpu_ops.hseqr_batched(dev(hh))
+    assert int(info2.abs().sum().item()) == 0
+    assert O.max_abs_dlambda(w2.cpu().numpy() / scale, np.linalg.eigvals(hh / scale)) < 1e-10
+
+
+def test_workspace_falls_back_to_passes_under_memory_pressure(gpu_ops, monkeypatch):
+    """ops._workspace halves its request down to the documented floor when the allocation fails (the n = 64 solver asks
+    for 15.5 KB per matrix of a pass): same spectra through the smaller workspace."""
+    rng = np.random.default_rng(680)
+    a = dev(rng.standard_normal((40000, 64, 64)) / 8)
+    w_ref, info_ref = gpu_ops.eig_general_batched(a)
+    gpu_ops.release_workspaces()
+    real_empty = torch.empty
+    need = gpu_ops.lib().egs_eig_workspace_bytes(1, 40000, 64)
+    calls = []
+
+    def stingy(size, *args, **kw):
+        if kw.get("dtype") == torch.uint8 and isinstance(size, int) and size > need // 2:
+            calls.append(size)
+            raise torch.cuda.OutOfMemoryError("simulated")
+        return real_empty(size, *args, **kw)
+
+    monkeypatch.setattr(torch, "empty", stingy)
+    w, info = gpu_ops.eig_general_batched(a)
+    monkeypatch.undo()
+    assert calls and int(info.abs().sum().item()) == 0
+    assert torch.equal(torch.view_as_real(w), torch.view_as_real(w_ref))      # passes do not change a bit
+    gpu_ops.release_workspaces()

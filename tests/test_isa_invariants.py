@@ -77,6 +77,22 @@ def test_in_flight_lds_operands_are_not_touched(asm, kernel):
             if ln and not ln.startswith(";") and not ln.startswith("."):
                 assert not (_vregs_of(ln) & flying), "in-flight LDS operand touched before it landed: " + ln
                 assert not ln.startswith("scratch_"), ln          # (the one branch in between guards the negligible-column fix-up)
+                mb = re.match(r"s_cbranch_\w+\s+(\.LBB\w+)", ln)
+                if mb:
+                    # the out-of-line side of that branch runs with the operands still in flight: same check there, up
+                    # to the jump back (or a wait that lands them)
+                    j = lines.index(mb.group(1) + ":") if (mb.group(1) + ":") in lines else None
+                    if j is None:
+                        j = next(x for x, l2 in enumerate(lines) if l2.startswith(mb.group(1) + ":"))
+                    j += 1
+                    while j < len(lines) and not lines[j].startswith("s_branch") and not lines[j].startswith("s_endpgm"):
+                        l2 = lines[j]
+                        if l2.startswith("s_waitcnt") and "lgkmcnt(0)" in l2:
+                            break
+                        if l2 and not l2.startswith(";") and not l2.startswith("."):
+                            assert not (_vregs_of(l2) & flying), "in-flight LDS operand touched out of line: " + l2
+                            assert not l2.startswith("scratch_"), l2
+                        j += 1
             i += 1
         assert landed
         batches += 1
@@ -94,3 +110,69 @@ def test_sweep_loops_have_no_scratch_traffic(asm):
                 depth = int(m.group(1)) if m else (0 if ln.startswith(".LBB") else depth)
             if ln.strip().startswith("scratch_"):
                 assert depth <= 2, (kernel, depth, ln)
+
+
+def _innermost_loop_of_each_line(lines):
+    """Loop header label of the innermost loop every line belongs to (None outside loops), from the block comments the
+    compiler emits ("=>This Inner Loop Header" / "in Loop: Header=BBx_y")."""
+    owner, cur, i = [], None, 0
+    while i < len(lines):
+        m = re.match(r"\.(LBB\w+):", lines[i])
+        if m:
+            j, text = i, lines[i]
+            while j + 1 < len(lines) and lines[j + 1].startswith(";"):
+                j += 1
+                text += " " + lines[j]
+            if "This Inner Loop Header" in text or "This Loop Header" in text:
+                cur = m.group(1)
+            else:
+                h = re.search(r"in Loop: Header=(BB\w+)", text)
+                cur = ("L" + h.group(1)) if h else None
+        owner.append(cur)
+        i += 1
+    return owner
+
+
+@pytest.mark.parametrize("kernel", ["_ZN3egs17eig_real64_kernelEPKdlilPdPiS2_iPyS2_", "_ZN3egs15hqr_real_kernelILb1EEEvPKdliPdPiiiPy",
+                                    "_ZN3egs15hqr_tail_kernelEPKdlPdPiPy"])
+def test_hand_predicated_stores_restore_the_loop_entry_exec(asm, kernel):
+    """lds_store3_where narrows EXEC with v_cmpx behind the compiler's back and restores it from the mask its
+    steady-state loop was entered with (read once in front of the loop).  That is correct as long as nothing else
+    inside that loop changes EXEC or the saved mask -- re-derived here from the emitted code, so a compiler that starts
+    predicating part of the loop body fails this test instead of corrupting EXEC silently."""
+    lines = [ln.strip() for ln in _kernel(asm, kernel)]
+    owner = _innermost_loop_of_each_line(lines)
+    sites = [i for i, ln in enumerate(lines) if ln.startswith("v_cmpx_")]
+    assert len(sites) >= 8
+    for i in sites:
+        m = re.fullmatch(r"s_mov_b64 exec, (s\[(\d+):(\d+)\])", lines[i + 3])
+        assert m, "predicated store does not end by restoring EXEC from an SGPR pair: " + lines[i + 3]
+        assert owner[i] is not None, "predicated store outside any loop"
+        saved = {int(m.group(2)), int(m.group(3))}
+        body = [k for k in range(len(lines)) if owner[k] == owner[i]]
+        hand = set()
+        for j in sites:
+            hand |= {j, j + 3}
+        open_regions = set()
+        for k in body:
+            ln = lines[k]
+            if not ln or ln.startswith(";") or ln.startswith("."):
+                continue
+            if k in sites:
+                assert not open_regions, f"v_cmpx reached inside a predicated region {open_regions}: {ln}"
+            if k in hand:
+                continue
+            ms = re.match(r"s_\w+_saveexec_b64 (s\[\d+:\d+\])", ln)
+            mo = re.match(r"s_or_b64 exec, exec, (s\[\d+:\d+\])", ln)
+            if ms:                                   # a compiler-made region (the rare tiny-column fix-up): must close
+                open_regions.add(ms.group(1))        # again before the next hand-predicated store
+                continue
+            if mo:
+                open_regions.discard(mo.group(1))
+                continue
+            dst = ln.split(None, 1)[1].split(",")[0] if " " in ln else ""
+            assert dst != "exec" and not ln.startswith("v_cmpx"), "EXEC written inside the loop of a hand-predicated store: " + ln
+            md = re.fullmatch(r"s\[(\d+):(\d+)\]|s(\d+)", dst)
+            if md and ln.startswith(("s_", "v_readlane", "v_readfirstlane")) and not ln.startswith("s_cmp"):
+                regs = set(range(int(md.group(1)), int(md.group(2)) + 1)) if md.group(1) else {int(md.group(3))}
+                assert not (regs & saved), "saved EXEC overwritten inside the loop: " + ln
