@@ -9,6 +9,7 @@
 //                         sum exp(fp32(score - m_t)) in fp64) so that the reference's fp32 max-subtraction
 //                         (eval_eig.py:62-74) and its masking quirks Q4/Q5 are reproduced exactly.
 //   3. eta_finalize     : eta_t = nu_t / nu_{t+1} [* exp(m_t - m_{t+1})], nu == 0 -> 2e-23 (linear, Q6).
+#include <type_traits>
 #include <stdlib.h>
 
 #include "egs_common.h"
@@ -113,18 +114,26 @@ struct ChunkSumArgs {
     int d_qk, num_heads, nchunks, chunk_tokens;
 };
 
-template <bool PHI>
+// WN = waves along the columns.  WN = 2: block tile 128 rows x 256 columns (2 x 2 waves, each 64 x 128) -- the form
+// rounds 1-3 had for every shape.  WN = 1: 256 rows x 128 columns (4 x 1 waves, each 64 x 128) for projections with at
+// most 128 columns (2 d_qk <= 128, e.g. the MQAR configs' d_qk = 64): in the 256-wide tile their second column half was
+// all padding, i.e. half of the matrix-core work and of the W staging computed zeros (round 4: 1.35 -> 0.7 ms on the
+// MQAR batch).  Same per-wave code either way; only the staging counts change (x: R / 32 float4 per thread, W: C / 32).
+template <bool PHI, int WN>
 __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __restrict__ x, int64_t m_rows, int d_model,
                                                                const float* __restrict__ wt, const float* __restrict__ bias,
                                                                int n_cols, float* __restrict__ out, ChunkSumArgs cs) {
-    __shared__ float as[kM2R][kM2LdA];
-    __shared__ __attribute__((aligned(16))) float bs[kM2K][kM2LdB];
+    constexpr int R = 64 * (4 / WN), C = 128 * WN, LdB = C + 4;
+    constexpr int NX = R / 32, NW = C / 32;                           // staged float4 per thread and k-stage
+    static_assert((WN == 1 ? R * kM2LdA : kM2K * LdB) >= 4 * 32 * kPatchLd, "an operand stage doubles as the epilogue patches");
+    __shared__ __attribute__((aligned(16))) float as[R * kM2LdA];
+    __shared__ __attribute__((aligned(16))) float bs[kM2K * LdB];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int kh = lane >> 5, l31 = lane & 31;
-    const int64_t row0 = (int64_t)blockIdx.x * kM2R;
-    const int col0 = blockIdx.y * kM2C;
+    const int64_t row0 = (int64_t)blockIdx.x * R;
+    const int col0 = blockIdx.y * C;
     f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -133,56 +142,55 @@ __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    // x stage: thread -> rows (tid>>3) + 32 e, k-quad (tid&7);  Wt stage: thread -> k rows (tid>>6) + 4 e, column quad (tid&63)
-    float4 xa0, xa1, xa2, xa3, wb0, wb1, wb2, wb3, wb4, wb5, wb6, wb7;
-    unsigned okm = 0u;                 // validity of the twelve staged loads (bits 0-3: x, 4-11: W)
+    // x stage: thread -> rows (tid>>3) + 32 e, k-quad (tid&7);  Wt stage: thread -> k rows (tid / (C/4)) + (1024/C) e,
+    // column quad (tid % (C/4))
+    float4 xa[NX], wb[NW];
+    unsigned okm = 0u;                 // validity of the staged loads (bits 0..NX-1: x, 8..8+NW-1: W)
     const int xr = tid >> 3, xq = tid & 7;
-    const int wk = tid >> 6, wq = tid & 63;
+    constexpr int WQ = C / 4, WKS = 256 / WQ;                         // column quads per k row, k rows per pass
+    const int wk = tid / WQ, wq = tid % WQ;
     // Loads always read a valid address and are zeroed when they are STORED to LDS one barrier later: a select right
     // after the load makes the wave wait for the data at once, i.e. turns the prefetch into a synchronous load.
-#define EGS_XLOAD(XA, E, K0)                                                                              \
-    {                                                                                                     \
-        const int64_t gr_ = row0 + xr + 32 * (E);                                                         \
-        const int gk_ = (K0) + xq * 4;                                                                    \
-        const bool ok_ = gr_ < m_rows && gk_ < d_model;                                                   \
-        XA = *reinterpret_cast<const float4*>(x + (ok_ ? gr_ * d_model + gk_ : 0));                       \
-        okm = ok_ ? (okm | (1u << (E))) : (okm & ~(1u << (E)));                                           \
-    }
-#define EGS_WLOAD(WB, E, K0)                                                                              \
-    {                                                                                                     \
-        const int gk_ = (K0) + wk + 4 * (E);                                                              \
-        const int gc_ = col0 + wq * 4;                                                                    \
-        const bool ok_ = gk_ < d_model && gc_ < n_cols;                                                   \
-        WB = *reinterpret_cast<const float4*>(wt + (ok_ ? (int64_t)gk_ * n_cols + gc_ : 0));              \
-        okm = ok_ ? (okm | (16u << (E))) : (okm & ~(16u << (E)));                                         \
-    }
-#define EGS_STAGE_LOAD(K0)                                                                                         \
-    EGS_XLOAD(xa0, 0, K0) EGS_XLOAD(xa1, 1, K0) EGS_XLOAD(xa2, 2, K0) EGS_XLOAD(xa3, 3, K0)                        \
-    EGS_WLOAD(wb0, 0, K0) EGS_WLOAD(wb1, 1, K0) EGS_WLOAD(wb2, 2, K0) EGS_WLOAD(wb3, 3, K0)                        \
-    EGS_WLOAD(wb4, 4, K0) EGS_WLOAD(wb5, 5, K0) EGS_WLOAD(wb6, 6, K0) EGS_WLOAD(wb7, 7, K0)
-#define EGS_XSTORE(XA, E)                               \
-    {                                                   \
-        const bool ok_ = (okm >> (E)) & 1u;             \
-        float* p_ = &as[xr + 32 * (E)][xq * 4];         \
-        p_[0] = ok_ ? XA.x : 0.0f;                      \
-        p_[1] = ok_ ? XA.y : 0.0f;                      \
-        p_[2] = ok_ ? XA.z : 0.0f;                      \
-        p_[3] = ok_ ? XA.w : 0.0f;                      \
-    }
-#define EGS_WSTORE(WB, E)                                                                           \
-    *reinterpret_cast<float4*>(&bs[wk + 4 * (E)][wq * 4]) =                                        \
-        ((okm >> (4 + (E))) & 1u) ? WB : make_float4(0.f, 0.f, 0.f, 0.f);
-#define EGS_STAGE_STORE()                                                                 \
-    EGS_XSTORE(xa0, 0) EGS_XSTORE(xa1, 1) EGS_XSTORE(xa2, 2) EGS_XSTORE(xa3, 3)           \
-    EGS_WSTORE(wb0, 0) EGS_WSTORE(wb1, 1) EGS_WSTORE(wb2, 2) EGS_WSTORE(wb3, 3)           \
-    EGS_WSTORE(wb4, 4) EGS_WSTORE(wb5, 5) EGS_WSTORE(wb6, 6) EGS_WSTORE(wb7, 7)
+    auto stage_load = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < NX; ++e) {
+            const int64_t gr = row0 + xr + 32 * e;
+            const int gk = k0 + xq * 4;
+            const bool ok = gr < m_rows && gk < d_model;
+            xa[e] = *reinterpret_cast<const float4*>(x + (ok ? gr * d_model + gk : 0));
+            okm = ok ? (okm | (1u << e)) : (okm & ~(1u << e));
+        }
+#pragma unroll
+        for (int e = 0; e < NW; ++e) {
+            const int gk = k0 + wk + WKS * e;
+            const int gc = col0 + wq * 4;
+            const bool ok = gk < d_model && gc < n_cols;
+            wb[e] = *reinterpret_cast<const float4*>(wt + (ok ? (int64_t)gk * n_cols + gc : 0));
+            okm = ok ? (okm | (256u << e)) : (okm & ~(256u << e));
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int e = 0; e < NX; ++e) {
+            const bool ok = (okm >> e) & 1u;
+            float* p = &as[(xr + 32 * e) * kM2LdA + xq * 4];
+            p[0] = ok ? xa[e].x : 0.0f;
+            p[1] = ok ? xa[e].y : 0.0f;
+            p[2] = ok ? xa[e].z : 0.0f;
+            p[3] = ok ? xa[e].w : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < NW; ++e)
+            *reinterpret_cast<float4*>(&bs[(wk + WKS * e) * LdB + wq * 4]) =
+                ((okm >> (8 + e)) & 1u) ? wb[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
 
-    EGS_STAGE_LOAD(0)
+    stage_load(0);
     for (int k0 = 0; k0 < d_model; k0 += kM2K) {
         __syncthreads();
-        EGS_STAGE_STORE()
+        stage_store();
         __syncthreads();
-        if (k0 + kM2K < d_model) { EGS_STAGE_LOAD(k0 + kM2K) }
+        if (k0 + kM2K < d_model) stage_load(k0 + kM2K);
         // LDS operands of two k-pairs (16 MFMAs) fetched while the previous two's MFMAs run: left alone, the scheduler sinks
         // each load to just before its consumer and every MFMA group waits an LDS round trip
         float a0[2][2], a1[2][2], bq[2][2][4];
@@ -190,10 +198,10 @@ __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __re
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int kk = 2 * (kb + u) + kh;
-                a0[buf][u] = as[wm * 64 + l31][kk];
-                a1[buf][u] = as[wm * 64 + 32 + l31][kk];
+                a0[buf][u] = as[(wm * 64 + l31) * kM2LdA + kk];
+                a1[buf][u] = as[(wm * 64 + 32 + l31) * kM2LdA + kk];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) bq[buf][u][c] = bs[kk][wn * 128 + 32 * c + l31];
+                for (int c = 0; c < 4; ++c) bq[buf][u][c] = bs[kk * LdB + wn * 128 + 32 * c + l31];
             }
         };
         fetch(0, 0);
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __re
     // Epilogue: bias + phi, then each 32x32 accumulator tile is transposed through a per-wave LDS patch so that the
     // global stores are 16 B per lane (8 lanes cover one 128-B row segment) instead of 16 dword stores per tile.
     __syncthreads();                                   // every wave is done with the operand stages
-    float* patch = &bs[0][0] + wave * (32 * kPatchLd);
+    float* patch = (WN == 1 ? as : bs) + wave * (32 * kPatchLd);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -253,12 +261,6 @@ __global__ __launch_bounds__(256, 2) void qk_proj_mfma2_kernel(const float* __re
             }
             wave_lds_sync();
         }
-#undef EGS_XLOAD
-#undef EGS_WLOAD
-#undef EGS_STAGE_LOAD
-#undef EGS_XSTORE
-#undef EGS_WSTORE
-#undef EGS_STAGE_STORE
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -566,19 +568,54 @@ __device__ __forceinline__ double exp_f64_fast(double x) {
     return ldexp(p, (int)n);
 }
 
+// exp(d) for the fp32 score differences d = score - max <= 0 of one row (eval_eig.py:72-77), in fp32 with an exact
+// range reduction: n = rint(d log2 e), f = d log2 e - n from two fused multiply-adds (log2 e split in hi + lo, so f is
+// good to half an ulp), 2^f on the hardware unit (v_exp_f32, 1 ulp), scaled by 2^n exactly.  1.5e-7 relative, against the
+// 1e-6 ... 2e-4 the reference's own fp32 scores put into these sums (tests/test_gpu_parity.py measures both against the
+// float64-exact formula); the row sum itself is accumulated in fp64.  Ten fp32 instructions instead of the ~20 fp64
+// ones of exp_f64_fast: the one-pass kernel below evaluates it once per causal score element.
+__device__ __forceinline__ float exp_f32_split(float d) {
+    d = fmaxf(d, -104.0f);                                            // 2^-150: below the smallest fp32 denormal
+    const float n = rintf(d * 1.44269502f);
+    float f = fmaf(d, 1.44269502f, -n);
+    f = fmaf(d, 1.92596299e-8f, f);
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+// One pass over the key blocks (round 4; rounds 1-3 made two: row maxima first, then the sums): every lane keeps a
+// running maximum and a running fp64 sum relative to it for its row and its quarter of the keys, and multiplies the sum
+// by exp(m_old - m_new) when a block raises the maximum (a wave-uniform branch: after the first blocks of a row it is
+// rarely taken).  m_old - m_new is formed in fp64 from two fp32 numbers, i.e. exactly, so the rescaled sum differs from
+// the two-pass one only by the rounding of that one exp.  Quirk Q5 (the zero-masked entries s > t take part in the row
+// maximum, eval_eig.py:59, :62) is the INITIAL value of the running maximum: 0 for every row but the last.
+// Half the matrix-core work of the two-pass form, and the epilogue is fp32 (exp_f32_split).
+//
+// Scheduling: a (b, h, 64-row tile) costs (tile index + 1) key blocks and lives ~25 us -- as one workgroup each, the chip
+// ran at 1.7 of 3 possible waves per SIMD (launch gaps between short-lived workgroups of very different lengths).  Now a
+// resident grid walks UNITS of equal cost: tile p of a sequence together with its mirror tile T-1-p (T + 1 blocks), big
+// tile first; grid-stride over identical units needs no queue.
 template <int J, int KB>
-__global__ __launch_bounds__(256) void softmax_nu_mfma_kernel(const float* __restrict__ qk, int64_t seqlen, int d_qk,
-                                                              int num_heads, double* __restrict__ nu,
+__global__ __launch_bounds__(256) void softmax_nu_mfma_kernel(const float* __restrict__ qk, int64_t nbh, int64_t seqlen,
+                                                              int d_qk, int num_heads, double* __restrict__ nu,
                                                               float* __restrict__ mrow) {
+    static_assert(KB == 64, "four 16-key tiles per block, one per wave's diagonal position");
     extern __shared__ __attribute__((aligned(16))) float ks2[];      // [4][KB][J + 4]
     constexpr int kLd = J + 4;
     constexpr int kV4 = (KB * J + 255) / 256;                         // float4 of the K block per thread
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const int h = blockIdx.y;
-    const int64_t b = blockIdx.z;
     const int hd = d_qk / num_heads;                                  // multiple of 4 (checked by the launcher)
-    const int64_t t0 = (int64_t)blockIdx.x * kNuRows;
+    const int ntile = (int)((seqlen + kNuRows - 1) / kNuRows);
+    const int npair = (ntile + 1) / 2;
+    for (int64_t unit = blockIdx.x; unit < nbh * npair; unit += gridDim.x) {
+    const int64_t bh = unit / npair;
+    const int pr = (int)(unit - bh * npair);
+    const int h = (int)(bh % num_heads);
+    const int64_t b = bh / num_heads;
+    for (int half = 0; half < 2; ++half) {
+    const int tile = half == 0 ? ntile - 1 - pr : pr;
+    if (half == 1 && tile == ntile - 1 - pr) break;                   // the middle tile of an odd count stands alone
+    const int64_t t0 = (int64_t)tile * kNuRows;
     const float* qbase = qk + b * seqlen * 2 * d_qk + (int64_t)h * hd;
     const float* kbase = qbase + d_qk;
     const int64_t t = t0 + 16 * w + c;                                // this lane's query row
@@ -591,7 +628,6 @@ __global__ __launch_bounds__(256) void softmax_nu_mfma_kernel(const float* __res
         const float v = qbase[tc * 2 * d_qk + (d < hd ? d : hd - 1)];
         qreg[j] = (d < hd && t < seqlen) ? v : 0.0f;
     }
-    const int64_t wave_tmax = t0 + 16 * w + 15;                       // last query row of this wave
     const int64_t s_end = (t0 + kNuRows < seqlen) ? t0 + kNuRows : seqlen;   // keys [0, s_end) are needed
 
     // K block of keys s0..s0+KB-1 as kV4 float4 per thread (key sr, dims 4 j..4 j+3), fetched a block ahead
@@ -608,82 +644,113 @@ __global__ __launch_bounds__(256) void softmax_nu_mfma_kernel(const float* __res
     };
     fetch(0);
 
-    float m_run = -INFINITY;
+    float m_run = (t < seqlen - 1) ? 0.0f : -INFINITY;                // Q5: the masked zeros of the row
     double sum_run = 0.0;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int64_t s0 = 0; s0 < s_end; s0 += KB) {
-            __syncthreads();                                          // previous block fully consumed
+    // NT score tiles (16 keys each) of the staged block, independent accumulator chains interleaved; then the online
+    // update with them.  DIAG: tile NT-1 straddles the diagonal (keys 16 w + 4 g + r against row 16 w + c).
+    auto block = [&](auto nt_tag, auto diag_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        constexpr bool DIAG = decltype(diag_tag)::value;
+        f32x4 acc[NT];
 #pragma unroll
-            for (int x = 0; x < kV4; ++x) {
-                const int idx = tid + 256 * x;
-                const int sr = idx / J, j = idx - sr * J;
-                if (idx < KB * J) {
-                    const bool ok = (4 * j < hd) && (s0 + sr < seqlen);
-                    ks2[(0 * KB + sr) * kLd + j] = ok ? kpre[x].x : 0.0f;
-                    ks2[(1 * KB + sr) * kLd + j] = ok ? kpre[x].y : 0.0f;
-                    ks2[(2 * KB + sr) * kLd + j] = ok ? kpre[x].z : 0.0f;
-                    ks2[(3 * KB + sr) * kLd + j] = ok ? kpre[x].w : 0.0f;
-                }
-            }
-            __syncthreads();
-            {                                                         // next block (or the first one of pass 2)
-                const int64_t sn = (s0 + KB < s_end) ? s0 + KB : 0;
-                fetch(sn);
-            }
-            // four score tiles (64 keys) at a time: independent accumulator chains keep the matrix pipe busy
+        for (int x = 0; x < NT; ++x) acc[x] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const float* kr = ks2 + (g * KB + c) * kLd;
 #pragma unroll
-            for (int tq = 0; tq < KB / 16; tq += 4) {
-                if (s0 + 16 * tq > wave_tmax) continue;               // wave-uniform: all four tiles above the diagonal
-                f32x4 acc[4];
+        for (int jj = 0; jj < J; jj += 4) {
+            float4 k4[NT];
 #pragma unroll
-                for (int x = 0; x < 4; ++x) acc[x] = {0.0f, 0.0f, 0.0f, 0.0f};
-                const float* kr = ks2 + (g * KB + 16 * tq + c) * kLd;
+            for (int x = 0; x < NT; ++x) k4[x] = *reinterpret_cast<const float4*>(kr + 16 * x * kLd + jj);
 #pragma unroll
-                for (int jj = 0; jj < J; jj += 4) {
-                    float4 k4[4];
+            for (int x = 0; x < NT; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].x, qreg[jj], acc[x], 0, 0, 0);
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) k4[x] = *reinterpret_cast<const float4*>(kr + 16 * x * kLd + jj);
+            for (int x = 0; x < NT; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].y, qreg[jj + 1], acc[x], 0, 0, 0);
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].x, qreg[jj], acc[x], 0, 0, 0);
+            for (int x = 0; x < NT; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].z, qreg[jj + 2], acc[x], 0, 0, 0);
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].y, qreg[jj + 1], acc[x], 0, 0, 0);
+            for (int x = 0; x < NT; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].w, qreg[jj + 3], acc[x], 0, 0, 0);
+        }
+        float sc[NT][4];
+        bool ok[NT][4];
+        float bm = m_run;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].z, qreg[jj + 2], acc[x], 0, 0, 0);
+        for (int x = 0; x < NT; ++x) {
+            sc[x][0] = acc[x].x, sc[x][1] = acc[x].y, sc[x][2] = acc[x].z, sc[x][3] = acc[x].w;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].w, qreg[jj + 3], acc[x], 0, 0, 0);
-                }
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const float sc[4] = {acc[x].x, acc[x].y, acc[x].z, acc[x].w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t sidx = s0 + 16 * (tq + x) + 4 * g + r;
-                        const bool ok = sidx <= t && t < seqlen;
-                        if (pass == 0) {
-                            m_run = ok ? fmaxf(m_run, sc[r]) : m_run;
-                        } else if (ok) {
-                            const float diff = __fsub_rn(sc[r], m_run);   // fp32, eval_eig.py:72
-                            const double e = exp_f64_fast((double)diff);  // :74-77
-                            sum_run += (e == e) ? e : 0.0;                // nan_to_num
-                        }
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                ok[x][r] = !(DIAG && x == NT - 1) || 4 * g + r <= c;
+                bm = ok[x][r] ? fmaxf(bm, sc[x][r]) : bm;
             }
         }
-        if (pass == 0) {
-            m_run = fmaxf(m_run, __shfl_xor(m_run, 16, 64));
-            m_run = fmaxf(m_run, __shfl_xor(m_run, 32, 64));
-            // zero-masked entries s > t take part in the row max (quirk Q5): present unless t == L-1
-            if (t < seqlen - 1) m_run = fmaxf(m_run, 0.0f);
+        if (__builtin_amdgcn_ballot_w64(bm > m_run) != 0ULL) {         // some row's maximum moved: rescale (rare later on)
+            if (bm > m_run) {
+                sum_run *= (m_run == -INFINITY) ? 0.0 : exp_f64_fast((double)m_run - (double)bm);
+                m_run = bm;
+            }
+        }
+        // all exponentials first (independent chains the scheduler can interleave), then the fp64 accumulation;
+        // branch-free: a per-element `if` serialises sixteen dependent ten-instruction chains behind sixteen branches
+        float ev[NT][4];
+#pragma unroll
+        for (int x = 0; x < NT; ++x) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp_f32_split(__fsub_rn(sc[x][r], m_run));   // fp32 difference, eval_eig.py:72
+                ev[x][r] = ok[x][r] ? fmaxf(e, 0.0f) : 0.0f;                 // maxnum drops a NaN: nan_to_num, :74-77
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < NT; ++x) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum_run += (double)ev[x][r];
+        }
+    };
+    using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>;
+    using T3 = std::integral_constant<int, 3>;
+    using T4 = std::integral_constant<int, 4>;
+    for (int64_t s0 = 0; s0 < s_end; s0 += KB) {
+        __syncthreads();                                              // previous block fully consumed
+#pragma unroll
+        for (int x = 0; x < kV4; ++x) {
+            const int idx = tid + 256 * x;
+            const int sr = idx / J, j = idx - sr * J;
+            if (idx < KB * J) {
+                const bool okk = (4 * j < hd) && (s0 + sr < seqlen);
+                ks2[(0 * KB + sr) * kLd + j] = okk ? kpre[x].x : 0.0f;
+                ks2[(1 * KB + sr) * kLd + j] = okk ? kpre[x].y : 0.0f;
+                ks2[(2 * KB + sr) * kLd + j] = okk ? kpre[x].z : 0.0f;
+                ks2[(3 * KB + sr) * kLd + j] = okk ? kpre[x].w : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (s0 + KB < s_end) fetch(s0 + KB);
+        if (s0 < t0) {                                                // block below the diagonal: every key <= every row
+            block(T4{}, std::false_type{});
+        } else {                                                      // the diagonal block: tiles 0..w, tile w masked
+            if (w == 0) block(T1{}, std::true_type{});
+            else if (w == 1) block(T2{}, std::true_type{});
+            else if (w == 2) block(T3{}, std::true_type{});
+            else block(T4{}, std::true_type{});
         }
     }
-    sum_run += __shfl_xor(sum_run, 16, 64);
-    sum_run += __shfl_xor(sum_run, 32, 64);
+    // the four lane groups of a row hold disjoint key subsets: combine (m, sum) pairs
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float mo = __shfl_xor(m_run, off, 64);
+        const double so = __shfl_xor(sum_run, off, 64);
+        const float mn = fmaxf(m_run, mo);
+        const double fa = (m_run == mn) ? 1.0 : ((m_run == -INFINITY) ? 0.0 : exp_f64_fast((double)m_run - (double)mn));
+        const double fb = (mo == mn) ? 1.0 : ((mo == -INFINITY) ? 0.0 : exp_f64_fast((double)mo - (double)mn));
+        sum_run = sum_run * fa + so * fb;
+        m_run = mn;
+    }
     if (g == 0 && t < seqlen) {
         const int64_t o = (b * num_heads + h) * seqlen + t;
         nu[o] = sum_run + (double)(seqlen - 1 - t);                   // masked entries contribute exp(0) = 1 each (Q4)
         mrow[o] = m_run;
     }
+    }   // half
+    }   // unit
 }
 
 // key block per LDS stage
@@ -695,9 +762,15 @@ static int softmax_nu_mfma_launch(const float* qk, int64_t nb, int64_t seqlen, i
     if (dyn > 48 * 1024)
         EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_nu_mfma_kernel<J, KB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    const dim3 grid((unsigned)((seqlen + kNuRows - 1) / kNuRows), (unsigned)num_heads, (unsigned)nb);
-    hipLaunchKernelGGL((softmax_nu_mfma_kernel<J, KB>), grid, dim3(256), dyn, stream, qk, seqlen, d_qk, num_heads, nu,
-                       mrow);
+    int per_cu = 0;
+    EGS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, softmax_nu_mfma_kernel<J, KB>, 256, dyn));
+    if (per_cu < 1) per_cu = 1;
+    const int64_t ntile = (seqlen + kNuRows - 1) / kNuRows;
+    const int64_t units = nb * num_heads * ((ntile + 1) / 2);
+    const int64_t resident = (int64_t)current_device_cus() * per_cu;
+    const dim3 grid((unsigned)(units < resident ? units : resident));
+    hipLaunchKernelGGL((softmax_nu_mfma_kernel<J, KB>), grid, dim3(256), dyn, stream, qk, nb * num_heads, seqlen, d_qk,
+                       num_heads, nu, mrow);
     return 0;
 }
 
@@ -1059,18 +1132,25 @@ int attn_eta_launch(bool softmax, const float* x, int64_t batch, int64_t seqlen,
         const float* xin = x + b0 * seqlen * d_model;
         const bool fused_csum = mfma2_ok && !softmax && (seqlen % 32 == 0);
         if (mfma2_ok) {
-            const dim3 mgrid((unsigned)((rows + kM2R - 1) / kM2R), (unsigned)((n_cols + kM2C - 1) / kM2C));
+            const bool narrow = n_cols <= 128;                         // 256 x 128 block tile instead of 128 x 256
+            const int tr = narrow ? 256 : 128, tc = narrow ? 128 : 256;
+            const dim3 mgrid((unsigned)((rows + tr - 1) / tr), (unsigned)((n_cols + tc - 1) / tc));
             ChunkSumArgs cs{nullptr, seqlen, d_qk, num_heads, nchunks, kScanChunk};
             if (fused_csum) {
                 cs.csum = csum;
                 EGS_HIP(hipMemsetAsync(csum, 0, (size_t)nb * nchunks * d_qk * sizeof(double), stream));
             }
-            if (softmax)
-                hipLaunchKernelGGL(qk_proj_mfma2_kernel<false>, mgrid, dim3(256), 0, stream, xin, rows, d_model, wt, b_qk,
-                                   n_cols, qk, cs);
-            else
-                hipLaunchKernelGGL(qk_proj_mfma2_kernel<true>, mgrid, dim3(256), 0, stream, xin, rows, d_model, wt, b_qk,
-                                   n_cols, qk, cs);
+#define EGS_PROJ_LAUNCH(PHI, WN)                                                                                          \
+    hipLaunchKernelGGL((qk_proj_mfma2_kernel<PHI, WN>), mgrid, dim3(256), 0, stream, xin, rows, d_model, wt, b_qk, n_cols, \
+                       qk, cs)
+            if (softmax) {
+                if (narrow) EGS_PROJ_LAUNCH(false, 1);
+                else EGS_PROJ_LAUNCH(false, 2);
+            } else {
+                if (narrow) EGS_PROJ_LAUNCH(true, 1);
+                else EGS_PROJ_LAUNCH(true, 2);
+            }
+#undef EGS_PROJ_LAUNCH
         } else if (softmax)
             hipLaunchKernelGGL(qk_proj_kernel<false>, pgrid, dim3(256), 0, stream, xin, rows, d_model, w_qk, b_qk,
                                n_cols, qk);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""K4 timing: softmax eta (projection + two-pass row statistics + finalize) on the matrix cores vs the VALU tile kernel
+"""K4 timing: softmax eta (projection + one-pass row statistics + finalize) on the matrix cores vs the VALU tile kernel
 (EGS_SOFTMAX_VALU=1); prints JSON lines."""
 import importlib, json, os, sys
 import torch
@@ -27,8 +27,8 @@ def main():
         w = torch.randn(2 * dqk, D, device="cuda") / D ** 0.5
         b = torch.randn(2 * dqk, device="cuda") * 0.1
         ms = timeit(lambda: ops.softmax_eta(x, w, b, dqk, H))
-        flops = 2 * B * H * L * (L + 1) / 2 * (dqk // H) * 2            # two passes of the causal score tiles
-        print(json.dumps({"B": B, "L": L, "D": D, "d_qk": dqk, "H": H, "ms": ms, "score_tflops": flops / ms / 1e9,
+        flops = B * H * L * (L + 1) / 2 * (dqk // H) * 2 + B * L * 2.0 * D * 2 * dqk   # one pass of causal score tiles + projection
+        print(json.dumps({"B": B, "L": L, "D": D, "d_qk": dqk, "H": H, "ms": ms, "tflops": flops / ms / 1e9,
                           "valu": bool(os.environ.get("EGS_SOFTMAX_VALU"))}), flush=True)
 
 
