@@ -1207,8 +1207,8 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_kernel(const float* __re
 template <int J, int NT>
 __global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t qk_bs, int64_t qk_ts, int64_t qk_hs,
-    const float* __restrict__ v, int64_t v_bs, int64_t v_ts, float* __restrict__ out, int64_t seqlen, int num_heads,
-    int hd, int dv, float scale) {
+    const float* __restrict__ v, int64_t v_bs, int64_t v_ts, float* __restrict__ out, int64_t nbatch, int64_t seqlen,
+    int num_heads, int hd, int dv, float scale) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     constexpr int kLd = J + 4;                                        // K stage: [4][64][J + 4]
     constexpr int kLv = NT * 16 + 4;                                  // V stage: [64][NT * 16 + 4]
@@ -1219,11 +1219,24 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int vchunks = (dv + NT * 16 - 1) / (NT * 16);
-    const int h = blockIdx.y / vchunks;
-    const int c0 = (blockIdx.y - h * vchunks) * (NT * 16);
+    // A resident grid walks units of equal cost -- the 64-row tile p of a (batch, head, column chunk) together with its
+    // mirror tile T-1-p (T + 1 key blocks), big tile first -- instead of one short-lived workgroup per tile (1 .. T blocks
+    // each): same scheduling as softmax_nu_mfma_kernel (attn_kernels.hip), where it took the chip from 1.7 to ~3 waves per SIMD.
+    const int ntile = (int)((seqlen + 63) / 64);
+    const int npair = (ntile + 1) / 2;
+    const int64_t nunits = nbatch * num_heads * vchunks * npair;
+    for (int64_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int64_t bhv = unit / npair;
+    const int pr = (int)(unit - bhv * npair);
+    const int hv = (int)(bhv % (num_heads * vchunks));
+    const int64_t b = bhv / (num_heads * vchunks);
+    const int h = hv / vchunks;
+    const int c0 = (hv - h * vchunks) * (NT * 16);
     const int cw = (dv - c0 < NT * 16) ? dv - c0 : NT * 16;           // live columns of this chunk
-    const int64_t b = blockIdx.z;
-    const int64_t t0 = (int64_t)blockIdx.x * 64;
+    for (int half = 0; half < 2; ++half) {
+    const int tile = half == 0 ? ntile - 1 - pr : pr;
+    if (half == 1 && tile == ntile - 1 - pr) break;                   // the middle tile of an odd count stands alone
+    const int64_t t0 = (int64_t)tile * 64;
     const float* qbase = q + b * qk_bs + (int64_t)h * qk_hs;
     const float* kbase = k + b * qk_bs + (int64_t)h * qk_hs;
     const float* vbase = v + b * v_bs + (int64_t)h * dv + c0;
@@ -1376,6 +1389,8 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
                 if (16 * nt + c < cw) dst[16 * nt + c] = o[nt][r] * ir;
         }
     }
+    }   // half
+    }   // unit
 }
 
 template <int J, int NT>
@@ -1387,9 +1402,15 @@ static int softmax_attn_fwd_mfma_launch(const float* q, const float* k, int64_t 
         EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_attn_fwd_mfma_kernel<J, NT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     const int vchunks = (dv + NT * 16 - 1) / (NT * 16);
-    const dim3 grid((unsigned)((seqlen + 63) / 64), (unsigned)(num_heads * vchunks), (unsigned)batch);
+    int per_cu = 0;
+    EGS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, softmax_attn_fwd_mfma_kernel<J, NT>, 256, dyn));
+    if (per_cu < 1) per_cu = 1;
+    const int64_t ntile = (seqlen + 63) / 64;
+    const int64_t units = batch * num_heads * vchunks * ((ntile + 1) / 2);
+    const int64_t resident = (int64_t)current_device_cus() * per_cu;
+    const dim3 grid((unsigned)(units < resident ? units : resident));
     hipLaunchKernelGGL((softmax_attn_fwd_mfma_kernel<J, NT>), grid, dim3(256), dyn, stream, q, k, qk_bs, qk_ts, qk_hs, v,
-                       v_bs, v_ts, out, seqlen, num_heads, hd, dv, scale);
+                       v_bs, v_ts, out, batch, seqlen, num_heads, hd, dv, scale);
     EGS_LAUNCH_CHECK();
     return 0;
 }

@@ -96,7 +96,11 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     // xGEEV-style scaling: matrices whose largest entry is outside [1e-100, 1e100] are scaled by a power of two so
     // that the unscaled reflector arithmetic (squares of entries) cannot overflow / underflow; the QR stage multiplies
     // the eigenvalues back.  The exponent travels in the info slot between the two kernels.
-    if (scale_exp != nullptr) {
+    // Without an exponent output (egs_hessenberg_batched: the caller wants a matrix similar to its input) the same
+    // scaling is applied and undone when the result is stored -- entries of 1e-220 otherwise gave a wrong reduction
+    // (their squares underflow), entries of 1e+220 an overflow.
+    int e_scale = 0;
+    {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
         int e = 0;
@@ -108,7 +112,11 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
                 if (inr) s[i * kHessLd + lane] = scalbn(s[i * kHessLd + lane], -e);
             wave_lds_sync();
         }
-        if (lane == 0) scale_exp[mat] = e;
+        if (scale_exp != nullptr) {
+            if (lane == 0) scale_exp[mat] = e;
+        } else if (e != kNonFinite) {
+            e_scale = e;
+        }
     }
 
     // ---- xGEBAL: permute rows/columns that isolate an eigenvalue to the ends, then scale the remaining block ----
@@ -352,7 +360,8 @@ __global__ __launch_bounds__(kHessWaves* kWave) void hess_real_kernel(
     // store the Hessenberg matrix densely (exact zeros below the subdiagonal)
     double* dst = hout + mat * (int64_t)n * n;
     for (int i = 0; i < n; ++i)
-        if (inr) dst[(int64_t)i * n + lane] = (i > lane + 1) ? 0.0 : s[i * kHessLd + lane];
+        if (inr) dst[(int64_t)i * n + lane] = (i > lane + 1) ? 0.0 : (e_scale ? scalbn(s[i * kHessLd + lane], e_scale)
+                                                                               : s[i * kHessLd + lane]);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -23,16 +23,19 @@ __global__ __launch_bounds__(kRegWaves* kWave, 2) void hess_reg_kernel(const dou
     double* dst = hout + mat * (int64_t)n * n;
     double A[16][4];
     // the output slot of this matrix doubles as the scratch of the permutation path
-    const int e = hess_reg_reduce(A, L, a + mat * stride, lda, smem_reg + (size_t)wave * kRegVec, dst,
-                                  scale_exp != nullptr, balance);
+    // always normalised inside (max |entry| in [1, 2), exact): without an exponent output (egs_hessenberg_batched: the
+    // caller wants a matrix similar to its input) the result is scaled back when it is stored -- entries of 1e-220
+    // otherwise gave a wrong reduction (their squares underflow), entries of 1e+220 an overflow
+    const int e = hess_reg_reduce(A, L, a + mat * stride, lda, smem_reg + (size_t)wave * kRegVec, dst, true, balance);
     if (scale_exp != nullptr && L.lane == 0) scale_exp[mat] = e;
+    const int back = (scale_exp == nullptr && e != kRegNonFinite) ? e : 0;
     // the Hessenberg matrix, dense, with exact zeros below the subdiagonal
 #pragma unroll
     for (int R = 0; R < 16; ++R)
 #pragma unroll
         for (int C = 0; C < 4; ++C) {
             const int row = 4 * R + L.q, col = 16 * C + L.c;
-            dst[(int64_t)row * n + col] = (row > col + 1) ? 0.0 : A[R][C];
+            dst[(int64_t)row * n + col] = (row > col + 1) ? 0.0 : (back ? scalbn(A[R][C], back) : A[R][C]);
         }
 }
 

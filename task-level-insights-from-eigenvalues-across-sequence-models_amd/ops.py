@@ -109,7 +109,7 @@ def eig_general_batched(a, workspace=None):
             need = lib().egs_eig_workspace_bytes(dtype, nmat, n)
             # real float64 input of order <= 64 is solved in passes over whatever the workspace holds (eigspec.h): under
             # memory pressure take less instead of failing (n = 64 asks for 15.5 KB per matrix of a pass)
-            floor = (lib().egs_eig_workspace_bytes(dtype, min(nmat, 32768), n)
+            floor = (lib().egs_eig_workspace_bytes(dtype, min(nmat, 4096), n)
                      if a.dtype == torch.float64 and n <= 64 else None)
             ws = _workspace(a.device, need, floor=floor)
         check(lib().egs_eig_general_batched(_ptr(a3), dtype, nmat, n, n, n * n, _ptr(w), _ptr(info), _ptr(ws),

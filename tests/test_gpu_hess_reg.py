@@ -359,10 +359,12 @@ def test_workspace_falls_back_to_passes_under_memory_pressure(gpu_ops, monkeypat
     gpu_ops.release_workspaces()
     real_empty = torch.empty
     need = gpu_ops.lib().egs_eig_workspace_bytes(1, 40000, 64)
+    floor = gpu_ops.lib().egs_eig_workspace_bytes(1, 4096, 64)      # what ops.eig_general_batched goes down to
+    assert floor < need // 4
     calls = []
 
     def stingy(size, *args, **kw):
-        if kw.get("dtype") == torch.uint8 and isinstance(size, int) and size > need // 2:
+        if kw.get("dtype") == torch.uint8 and isinstance(size, int) and size > need // 4:
             calls.append(size)
             raise torch.cuda.OutOfMemoryError("simulated")
         return real_empty(size, *args, **kw)
@@ -370,6 +372,6 @@ def test_workspace_falls_back_to_passes_under_memory_pressure(gpu_ops, monkeypat
     monkeypatch.setattr(torch, "empty", stingy)
     w, info = gpu_ops.eig_general_batched(a)
     monkeypatch.undo()
-    assert calls and int(info.abs().sum().item()) == 0
+    assert len(calls) >= 2 and int(info.abs().sum().item()) == 0
     assert torch.equal(torch.view_as_real(w), torch.view_as_real(w_ref))      # passes do not change a bit
     gpu_ops.release_workspaces()

@@ -308,7 +308,7 @@ def test_softmax_attention_matches_golden(gpu_ops, golden, case):
     err_ref = np.max(np.abs(ref[ok] - exact[ok]) / np.abs(exact[ok]))
     err_hip = np.max(np.abs(eta[ok] - exact[ok]) / np.abs(exact[ok]))
     assert err_ref < 3e-4                                     # the reference's own distance (1.2e-6 / 1.5e-5 / 1.9e-4)
-    assert err_hip <= 2.0 * err_ref + 2e-7, (err_hip, err_ref)
+    assert err_hip <= 2.0 * err_ref + 1e-6, (err_hip, err_ref)       # 1e-6: the fp32 exponential's own floor (3e-7)
 
 
 @pytest.mark.parametrize("seqlen,d,d_qk,h", [(130, 24, 48, 2), (64, 16, 16, 1), (257, 40, 160, 1), (2, 8, 8, 4),
@@ -713,3 +713,49 @@ def test_eig_real_work_queue_covers_every_matrix(gpu_ops, n, nmat):
     assert float(((w * w).sum(dim=1).real - tr2).abs().max()) < 1e-9
     idx = torch.tensor([0, 1, nmat // 2, nmat - 2, nmat - 1], device="cuda")
     assert O.max_abs_dlambda(w[idx].cpu().numpy(), O.eigvals_dense(a[idx].cpu().numpy())) < 1e-9
+
+
+@pytest.mark.parametrize("kind", ["rising", "falling", "spiky", "huge_negative", "ragged"])
+def test_softmax_one_pass_kernel_on_adversarial_score_profiles(gpu_ops, kind):
+    """K4 keeps a running row maximum and rescales its running sum when a key block raises it (round 4: one pass over
+    the score tiles instead of two).  Profiles that stress exactly that: maxima that rise with every key block (rescale
+    in every block), fall from the first key on (never again), single spikes late in the row, scores so negative that
+    every causal term underflows next to the masked zeros of quirk Q5, and a length that ends inside a tile.  Through the
+    (q, k) entry, against the oracle's restatement of the notebook cell / eval_eig.py:43-95."""
+    rng = np.random.default_rng(len(kind) * 31)
+    B, L, H, hd = 2, (391 if kind == "ragged" else 320), 2, 16
+    q = rng.standard_normal((B, L, H, hd)).astype(np.float32)
+    k = rng.standard_normal((B, L, H, hd)).astype(np.float32)
+    ramp = np.linspace(0.0, 1.0, L, dtype=np.float32)[None, :, None, None]
+    if kind == "rising":
+        k = k * 0.05 + 6.0 * ramp * np.sign(q.mean(axis=1, keepdims=True))       # later keys score higher and higher
+        q = np.abs(q) * np.sign(q.mean(axis=1, keepdims=True))
+    elif kind == "falling":
+        k = k * 0.05 - 6.0 * ramp * np.sign(q.mean(axis=1, keepdims=True))
+        q = np.abs(q) * np.sign(q.mean(axis=1, keepdims=True))
+    elif kind == "spiky":
+        k[:, 250] *= 40.0                                                        # one key far above the rest, late
+        k[:, 3] *= 25.0
+    elif kind == "huge_negative":
+        q = np.abs(q) + 1.0
+        k = -(np.abs(k) + 1.0) * 8.0                                             # every score << 0: the masked zeros are the row maximum
+    want = O.eta_softmax_from_qk(q, k)[..., 0]
+    got = gpu_ops.softmax_eta_from_qk(dev(q), dev(k)).cpu().numpy()
+    assert got.shape == want.shape and np.all(np.isfinite(got) == np.isfinite(want))
+    # Scores of several hundred carry fp32 rounding of 3e-5 into exp(score - max), in the reference's arithmetic (which
+    # the oracle restates) as much as in the kernel's -- but not the same rounding: the kernel subtracts the RUNNING
+    # maximum in fp32 and rescales exactly.  So, as in the golden test, both are measured against the float64 value of
+    # the same formula; the kernel may be at most twice as far from it as the reference's arithmetic is.
+    q64, k64 = q.astype(np.float64), k.astype(np.float64)
+    sc = np.einsum("bthd,bshd->btsh", q64, k64)
+    tril = np.tril(np.ones((L, L)))
+    sc = sc * tril[None, :, :, None]
+    m = sc.max(axis=2)
+    nu = (np.exp(sc - m[:, :, None, :]) * tril[None, :, :, None]).sum(axis=2) + (L - 1 - np.arange(L))[None, :, None]
+    with np.errstate(over="ignore", invalid="ignore"):
+        exact = nu[:, :-1] / nu[:, 1:] * np.exp(m[:, :-1] - m[:, 1:])
+    ok = np.isfinite(exact) & (exact != 0) & np.isfinite(want) & (want != 0)
+    err_ref = np.max(np.abs(want[ok] - exact[ok]) / np.abs(exact[ok]))
+    err_hip = np.max(np.abs(got[ok] - exact[ok]) / np.abs(exact[ok]))
+    assert err_ref < 1e-3, err_ref
+    assert err_hip <= 2.0 * err_ref + 1e-6, (err_hip, err_ref)       # 1e-6: the fp32 exponential's own floor (3e-7)
