@@ -712,7 +712,9 @@ __device__ __forceinline__ void lds_read3x2(const double* p, const double* q, do
 }
 
 // Predicated store of three doubles p[0], p[S1], p[2 S1] by the lanes with e <= thr (GE: e >= thr; thr wave-uniform): v_cmpx writes
-// EXEC directly, the stores run under it, EXEC goes back to `full` -- two instructions of overhead instead of the
+// EXEC directly, the stores run under it (three ds_write_b64: 3 x 6 store-path cycles against 13 + 6 for ds_write2_b64 +
+// ds_write_b64 -- measured 2.1 % of the C2 step, round 4; -DEGS_STORE3_WRITE2 restores the pair form), EXEC goes back
+// to `full` -- two instructions of overhead instead of the
 // compare + s_and_saveexec + s_cbranch_execz + s_or the compiler emits for `if (e <= thr) { ... }`, and no branch.
 // `full` is the EXEC mask the enclosing steady-state loop was ENTERED with (read once in front of the loop, qr2_segment:
 // no instruction per iteration), so the statement stays correct if a compiler ever runs that loop under a predicate;
@@ -725,23 +727,39 @@ __device__ __forceinline__ void lds_store3_where(int e, int thr, double* p, doub
     static_assert(2 * S1 < 256, "ds_write2_b64 offsets are 8-bit, in units of 8 bytes");
     if (GE)
         asm volatile(
+#ifndef EGS_STORE3_WRITE2
+            "v_cmpx_le_i32_e32 vcc, %[thr], %[e]\n\t"
+            "ds_write_b64 %[p], %[v0]\n\t"
+            "ds_write_b64 %[p], %[v1] offset:%[o1b]\n\t"
+            "ds_write_b64 %[p], %[v2] offset:%[o2]\n\t"
+            "s_mov_b64 exec, %[full]"
+#else
             "v_cmpx_le_i32_e32 vcc, %[thr], %[e]\n\t"
             "ds_write2_b64 %[p], %[v0], %[v1] offset1:%[o1]\n\t"
             "ds_write_b64 %[p], %[v2] offset:%[o2]\n\t"
             "s_mov_b64 exec, %[full]"
+#endif
             :
             : [e] "v"(e), [thr] "s"(thr), [p] "v"((unsigned)(uintptr_t)p), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2),
-              [o1] "n"(S1), [o2] "n"(2 * S1 * 8), [full] "s"(full)
+              [o1] "n"(S1), [o1b] "n"(S1 * 8), [o2] "n"(2 * S1 * 8), [full] "s"(full)
             : "vcc", "memory");
     else
         asm volatile(
+#ifndef EGS_STORE3_WRITE2
+            "v_cmpx_ge_i32_e32 vcc, %[thr], %[e]\n\t"
+            "ds_write_b64 %[p], %[v0]\n\t"
+            "ds_write_b64 %[p], %[v1] offset:%[o1b]\n\t"
+            "ds_write_b64 %[p], %[v2] offset:%[o2]\n\t"
+            "s_mov_b64 exec, %[full]"
+#else
             "v_cmpx_ge_i32_e32 vcc, %[thr], %[e]\n\t"
             "ds_write2_b64 %[p], %[v0], %[v1] offset1:%[o1]\n\t"
             "ds_write_b64 %[p], %[v2] offset:%[o2]\n\t"
             "s_mov_b64 exec, %[full]"
+#endif
             :
             : [e] "v"(e), [thr] "s"(thr), [p] "v"((unsigned)(uintptr_t)p), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2),
-              [o1] "n"(S1), [o2] "n"(2 * S1 * 8), [full] "s"(full)
+              [o1] "n"(S1), [o1b] "n"(S1 * 8), [o2] "n"(2 * S1 * 8), [full] "s"(full)
             : "vcc", "memory");
 }
 

@@ -145,14 +145,16 @@ def test_hand_predicated_stores_restore_the_loop_entry_exec(asm, kernel):
     sites = [i for i, ln in enumerate(lines) if ln.startswith("v_cmpx_")]
     assert len(sites) >= 8
     for i in sites:
-        m = re.fullmatch(r"s_mov_b64 exec, (s\[(\d+):(\d+)\])", lines[i + 3])
-        assert m, "predicated store does not end by restoring EXEC from an SGPR pair: " + lines[i + 3]
+        close = next((j for j in range(i + 1, i + 6) if lines[j].startswith("s_mov_b64 exec,")), None)
+        assert close is not None and all(lines[j].startswith("ds_write") for j in range(i + 1, close)), lines[i:i + 6]
+        m = re.fullmatch(r"s_mov_b64 exec, (s\[(\d+):(\d+)\])", lines[close])
+        assert m, "predicated store does not end by restoring EXEC from an SGPR pair: " + lines[close]
         assert owner[i] is not None, "predicated store outside any loop"
         saved = {int(m.group(2)), int(m.group(3))}
         body = [k for k in range(len(lines)) if owner[k] == owner[i]]
         hand = set()
         for j in sites:
-            hand |= {j, j + 3}
+            hand |= {j, next(x for x in range(j + 1, j + 6) if lines[x].startswith("s_mov_b64 exec,"))}
         open_regions = set()
         for k in body:
             ln = lines[k]
