@@ -92,7 +92,9 @@ int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const do
  * occupancy -- same arithmetic, bit-identical spectra.  The workspace provides a 32 KB scratch slot per resident wavefront
  * plus those records; a smaller workspace than the query's value is accepted: records for >= min(nmat, 32768) matrices
  * give several passes, less gives the one-kernel form, which only needs the slots (it limits the number of resident
- * wavefronts, at least 4 slots + 256 bytes).  Other n <= 64, real or complex, run LDS-resident in two
+ * wavefronts, at least 4 slots + 256 bytes).  Spectra and info do not depend on the workspace size by a single bit; the
+ * trade is memory against throughput (C2's 524288 matrices: 8.2 GB for one pass of the two-phase form; the Python
+ * binding halves its request down to 4096 matrices' worth when the allocation fails).  Other n <= 64, real or complex, run LDS-resident in two
  * kernels (one wavefront per matrix, Hessenberg matrices of a chunk in the workspace); larger n (<= 1024; the reference's S4
  * state_dim 128 / 512 and config C5's 256) run the level-3 path: blocked Householder reduction with fp64 matrix-core panel
  * updates, then small-bulge multishift QR (one workgroup of 16 wavefronts per matrix, working copy in the workspace).
@@ -123,8 +125,12 @@ int egs_hseqr_general_batched(double* h, int64_t nmat, int n, double* w, int32_t
 /* The two stages of the real LDS-resident solver (dtype EGS_F64, n <= 64), exposed separately like LAPACK's
  * xGEHRD / xHSEQR so that callers (and bench.py) can time or reuse them individually.
  *   egs_hessenberg_batched : a -> h, double[nmat, n, n] row-major upper-Hessenberg (exact zeros below the
- *                            subdiagonal); same eigenvalues as a.
- *   egs_hseqr_batched      : h (as produced above) -> w, info.  `queue` is NULL or 8 bytes of device scratch: with
+ *                            subdiagonal); orthogonally similar to a.  Any finite scale: the reduction works on a
+ *                            power-of-two multiple of a (so that squares of entries neither under- nor overflow) and
+ *                            scales the result back exactly.
+ *   egs_hseqr_batched      : h -> w, info.  h is any upper-Hessenberg matrix (the output above or the caller's own),
+ *                            at any finite scale: at n = 64 the kernel normalises it to max |entry| in [1, 2) first --
+ *                            its deflation and tiny-column thresholds are absolute -- and multiplies the eigenvalues back.  `queue` is NULL or 8 bytes of device scratch: with
  *                            it the kernel runs as one resident set of wavefronts that take matrices from a work
  *                            queue (what egs_eig_general_batched does); without it, one matrix per wavefront. */
 int egs_hessenberg_batched(const double* a, int64_t nmat, int n, int lda, int64_t stride, double* h,
