@@ -913,6 +913,266 @@ __device__ __forceinline__ void qr2_segment(Qr2Lane& S, int t0, const int t1) {
     for (int t = t0; t < t1; ++t) qr2_iter<false, R2, C2, V>(S, t, false, false, false, 0.0, 0.0, 0.0, full);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the MERGED iteration -- two sub-passes instead of three for windows of 33 .. 59 rows.
+//
+// Row and column operations apply the same formula n_j = x_j - (x_0 + u_1 x_1 + u_2 x_2) t_j to a triple of elements
+// that differ only in base address and stride, and a bulge needs R + C = (i - k + 2) + (k + 4 - l) = window + 6 <= 64
+// triples per iteration: two passes of a 32-lane group hold them.  What the fixed lane ownership of qr2_iter cannot give
+// is the one ordering constraint: the corner (rows k..k+3 x columns k-1..k+2) gets the row operation first, so all its
+// COLUMN lanes must sit in the earlier pass and all its ROW lanes in the later one.  Moving primaries do:
+//   pass A, lane j:  the MOVING column k + 30 - j  (rows k..k+2; valid while <= i; lanes 28..31 are the corner columns)
+//                    or, once that column has left the window, the FIXED top row l + j  (columns k..k+2; valid once
+//                    <= k - 29);
+//   pass B, lane j:  the FIXED right column i - j  (valid while >= k + 31, i.e. not covered by pass A)
+//                    or the MOVING bottom row k - 28 + j  (valid while l <= row <= i; lanes 28..31 are the corner rows).
+// For a window of <= 59 rows the two roles of a lane never overlap in time (brute-forced for every (l, i, m, t):
+// coverage, disjointness, corner order), every element receives the same operations in the same order as in
+// qr2_iter -- the spectra are bit-identical -- and a lane switches role at most once per sweep, by a compare of the
+// iteration counter with a per-lane constant.  Per pass: two address selects, one threshold select, two address adds
+// (per-lane strides: no immediate offsets), pointer bumps; one sub-pass (3 reads, 3 stores, 6 FMAs) less per iteration.
+// ---------------------------------------------------------------------------------------------------
+struct Qr2M {
+    unsigned pa1, pa2, pb1, pb2;   // LDS byte addresses of the four roles' first elements in the current iteration
+    unsigned bp;                   // &H(k, k-1): the bulge column
+    int hiA1, loA2;                // pass A: moving column valid <=> t <= hiA1; fixed top row valid <=> t >= loA2
+    int hiB1, loB2, hiB2;          // pass B: fixed right column valid <=> t <= hiB1; moving bottom row <=> loB2 <= t <= hiB2
+    unsigned live;                 // 1 while the lane's group is chasing (pointers advance), 0 while parked
+};
+
+template <int S1>
+__device__ __forceinline__ void lds_issue_b3_a3(unsigned b, unsigned p0, unsigned p1, unsigned p2, double& a0, double& a1,
+                                                double& a2, double& x0, double& x1, double& x2) {
+    asm volatile(
+        "ds_read_b64 %0, %6\n\t"
+        "ds_read_b64 %1, %6 offset:%10\n\t"
+        "ds_read_b64 %2, %6 offset:%11\n\t"
+        "ds_read_b64 %3, %7\n\t"
+        "ds_read_b64 %4, %8\n\t"
+        "ds_read_b64 %5, %9\n\t"
+        "s_waitcnt lgkmcnt(3)"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(x0), "=&v"(x1), "=&v"(x2)
+        : "v"(b), "v"(p0), "v"(p1), "v"(p2), "n"(S1 * 8), "n"(S1 * 16)
+        : "memory");
+}
+
+__device__ __forceinline__ void lds_read3_a3(unsigned p0, unsigned p1, unsigned p2, double& x0, double& x1, double& x2) {
+    asm volatile(
+        "ds_read_b64 %0, %3\n\t"
+        "ds_read_b64 %1, %4\n\t"
+        "ds_read_b64 %2, %5\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2)
+        : "v"(p0), "v"(p1), "v"(p2)
+        : "memory");
+}
+
+// lanes with e >= thr store (v0, v1, v2) to (p0, p1, p2); EXEC goes back to the loop-entry mask (see lds_store3_where)
+__device__ __forceinline__ void lds_store3_a3_where(int e, int thr, unsigned p0, unsigned p1, unsigned p2, double v0,
+                                                    double v1, double v2, unsigned long long full) {
+    asm volatile(
+        "v_cmpx_le_i32_e32 vcc, %[thr], %[e]\n\t"
+        "ds_write_b64 %[p0], %[v0]\n\t"
+        "ds_write_b64 %[p1], %[v1]\n\t"
+        "ds_write_b64 %[p2], %[v2]\n\t"
+        "s_mov_b64 exec, %[full]"
+        :
+        : [e] "v"(e), [thr] "s"(thr), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2),
+          [full] "s"(full)
+        : "vcc", "memory");
+}
+
+// an LDS byte address as the pointer the immediate-offset helpers take (they only use its low 32 bits)
+__device__ __forceinline__ const double* as_lds(unsigned a) { return reinterpret_cast<const double*>((uintptr_t)a); }
+
+__device__ __forceinline__ void lds_store1_a(unsigned p, double v) {
+    asm volatile("ds_write_b64 %0, %1" : : "v"(p), "v"(v) : "memory");
+}
+
+// One merged iteration.  GEN as in qr2_iter: some group takes its first or its last step (`first`, `last` per lane,
+// uniform per group; `top`: the sweep starts at the top of the window, column l-1 does not exist).
+// SA / SB: some lane may be in its second role in pass A (fixed top row) / its first role in pass B (fixed right column)
+// in this segment of the sweep; without them the pass has one role, one stride, and no selects.
+template <bool GEN, bool SA, bool SB, class V>
+__device__ __forceinline__ void qr2_iter_m(Qr2M& M, const int t, const int j, const bool first, const bool last,
+                                           const bool top, const double v0, const double v1, const double v2,
+                                           const unsigned long long full = ~0ULL) {
+    constexpr int SR = V::kSR, SC = V::kSC;
+    constexpr unsigned kSR8 = SR * 8, kSC8 = SC * 8, kDiag8 = (SR + SC) * 8;
+    // ---- pass A: moving columns | fixed top rows ----
+    const bool selA = SA && t >= M.loA2;
+    const unsigned pa = selA ? M.pa2 : M.pa1;
+    const unsigned sa = selA ? kSC8 : kSR8;
+    const int thrA = selA ? kNever : M.hiA1;
+    unsigned pa_1 = 0, pa_2 = 0;
+    double a0, a1, a2, x0, x1, x2;
+    if (SA) {
+        pa_1 = pa + sa;
+        pa_2 = pa_1 + sa;
+        lds_issue_b3_a3<SR>(M.bp, pa, pa_1, pa_2, a0, a1, a2, x0, x1, x2);
+    } else {                                                           // one role, one stride: immediate offsets
+        lds_issue3x2<SR>(as_lds(M.bp), as_lds(pa), a0, a1, a2, x0, x1, x2);
+    }
+    if (GEN) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2));
+        a0 = first ? v0 : a0;
+        a1 = first ? v1 : a1;
+        a2 = first ? v2 : (last ? 0.0 : a2);
+        x2 = last ? 0.0 : x2;
+    }
+    double t1, t2, t3, u1, u2;
+    larfg3_coeffs(a0, a1, a2, t1, t2, t3, u1, u2);
+    if (!GEN) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(t1));
+    {
+        const double sum = fma(u2, x2, fma(u1, x1, x0));
+        const double n0 = fma(-sum, t1, x0), n1 = fma(-sum, t2, x1), n2 = fma(-sum, t3, x2);
+        if (!GEN) {
+            if (SA) lds_store3_a3_where(thrA, t, pa, pa_1, pa_2, n0, n1, n2, full);
+            else lds_store3_where<SR, true>(thrA, t, const_cast<double*>(as_lds(pa)), n0, n1, n2, full);
+        } else {
+            // a first step at the top of the window: column l-1 (lane 31 of the moving columns) is outside it
+            const bool ok = thrA >= t && !(first && top && !selA && j == 31);
+            if (ok) {
+                lds_store1_a(pa, n0);
+                lds_store1_a(pa_1, n1);
+                if (!last) lds_store1_a(pa_2, n2);
+            }
+        }
+    }
+    wave_lds_sync();
+    // ---- pass B: fixed right columns | moving bottom rows ----
+    const bool inB2 = t >= M.loB2;                                     // the lane's bottom row has entered the window
+    const bool selB = !SB || inB2;
+    const unsigned pb = selB ? M.pb2 : M.pb1;
+    const unsigned sb = selB ? kSC8 : kSR8;
+    const int thrB = inB2 ? M.hiB2 : (SB ? M.hiB1 : -kNever);
+    unsigned pb_1 = 0, pb_2 = 0;
+    double c0, c1, c2;
+    if (SB) {
+        pb_1 = pb + sb;
+        pb_2 = pb_1 + sb;
+        lds_read3_a3(pb, pb_1, pb_2, c0, c1, c2);
+    } else {
+        lds_read3<SC>(as_lds(pb), c0, c1, c2);
+    }
+    if (GEN) c2 = last ? 0.0 : c2;
+    {
+        const double sum = fma(u2, c2, fma(u1, c1, c0));
+        const double n0 = fma(-sum, t1, c0), n1 = fma(-sum, t2, c1), n2 = fma(-sum, t3, c2);
+        if (!GEN) {
+            if (SB) lds_store3_a3_where(thrB, t, pb, pb_1, pb_2, n0, n1, n2, full);
+            else lds_store3_where<SC, true>(thrB, t, const_cast<double*>(as_lds(pb)), n0, n1, n2, full);
+        } else if (thrB >= t) {
+            lds_store1_a(pb, n0);
+            lds_store1_a(pb_1, n1);
+            if (!last) lds_store1_a(pb_2, n2);
+        }
+    }
+    wave_lds_sync();
+    // ---- the bulge moves one row down (a group parks where its last step left it) ----
+    const unsigned adv = (GEN && last) ? 0u : M.live;
+    M.pa1 += adv * kDiag8;
+    M.pa2 += adv * kSC8;
+    M.pb1 += adv * kSR8;
+    M.pb2 += adv * kDiag8;
+    M.bp += ((GEN && (first || last)) ? 0u : M.live) * kDiag8;   // bp starts at &H(m+1, m): the first step does not read it
+}
+
+template <bool SA, bool SB, class V>
+__device__ __forceinline__ void qr2_segment_m(Qr2M& M, int t0, const int t1, const int j) {
+    const unsigned long long full = __builtin_amdgcn_read_exec();
+    for (int t = t0; t < t1; ++t) qr2_iter_m<false, SA, SB, V>(M, t, j, false, false, false, 0.0, 0.0, 0.0, full);
+}
+
+// One sweep with merged iterations (window of 33 .. 59 rows); same special iterations, start vectors and parking as
+// qr2_sweep.
+template <class V>
+__device__ __forceinline__ void qr2_sweep_m(const V& H, const int l, const int i, const int m, const int lane, double v0,
+                                            double v1, double v2, const double rt1r, const double rt1i,
+                                            const double rt2r, const double rt2i) {
+    const int g = lane >> 5, j = lane & 31;
+    const bool two = (m == l);
+    const int nA = i - m;                                   // steps of one bulge: k = m .. i-1
+    const int T = nA + (two ? kBulgeDist : 0);
+    Qr2M M;
+    M.pa1 = lds_addr(&H.at(m, m + 30 - j));                 // (addresses of lanes that never become valid may lie outside
+    M.pa2 = lds_addr(&H.at(l + j, m));                      //  the array: they are only ever loaded from, and LDS loads
+    M.pb1 = lds_addr(&H.at(m, i - j));                      //  beyond the allocation return zero)
+    M.pb2 = lds_addr(&H.at(m - 28 + j, m));
+    M.bp = lds_addr(&H.at(m + 1, m));
+    const int off = kBulgeDist * g;                         // the trailing group is `off` iterations behind
+    const int hiA1 = i - 30 + j - m + off, loA2 = l + j + 29 - m + off;
+    const int hiB1 = i - j - 31 - m + off, loB2 = l + 28 - j - m + off, hiB2 = i + 28 - j - m + off;
+    const bool liveA = g == 0;
+    M.hiA1 = liveA ? hiA1 : -kNever;
+    M.loA2 = liveA ? loA2 : kNever;
+    M.hiB1 = liveA ? hiB1 : -kNever;
+    M.loB2 = liveA ? loB2 : kNever;
+    M.hiB2 = liveA ? hiB2 : -kNever;
+    M.live = liveA ? 1u : 0u;
+    const int tLastA = nA - 1, tFirstB = two ? kBulgeDist : T, tLastB = two ? nA - 1 + kBulgeDist : T;
+    const int tA2 = l + 29 - m;                              // first iteration in which some lane's top row is valid (g = 0, j = 0)
+    const int tB1 = i - 31 - m + (two ? kBulgeDist : 0);     // last iteration in which some lane's right column is (j = 0)
+    int t = 0;
+    while (t < T) {
+        int tg = tLastB;
+        if (tLastA >= t) tg = min(tg, tLastA);
+        if (tFirstB >= t) tg = min(tg, tFirstB);
+        if (t == 0) tg = 0;
+        // steady-state iterations t .. tg-1, cut into segments by which second roles can occur: fixed right columns
+        // (pass B) while t <= tB1, fixed top rows (pass A) from t >= tA2 on
+        while (t < tg) {
+            const bool sb = t <= tB1, sa = t >= tA2;
+            int e = tg;
+            if (sb) e = min(e, tB1 + 1);
+            if (!sa) e = min(e, tA2);
+            if (sa) {
+                if (sb) qr2_segment_m<true, true, V>(M, t, e, j);
+                else qr2_segment_m<true, false, V>(M, t, e, j);
+            } else {
+                if (sb) qr2_segment_m<false, true, V>(M, t, e, j);
+                else qr2_segment_m<false, false, V>(M, t, e, j);
+            }
+            t = e;
+        }
+        if (t >= T) break;
+        const bool fA = t == 0, lA = t == tLastA, fB = t == tFirstB, lB = t == tLastB;
+        if (fB) {
+            // the trailing bulge starts at row m on the matrix as the leading bulge left it (see qr2_sweep)
+            const double hmm = H.at(m, m), hm1m = H.at(m + 1, m), hm1m1 = H.at(m + 1, m + 1);
+            double s = fabs(hmm - rt2r) + fabs(rt2i) + fabs(hm1m);
+            double rs = fast_rcp(s);
+            const double h21s = hm1m * rs;
+            v0 = h21s * H.at(m, m + 1) + (hmm - rt1r) * ((hmm - rt2r) * rs) - rt1i * (rt2i * rs);
+            v1 = h21s * (hmm + hm1m1 - rt1r - rt2r);
+            v2 = h21s * H.at(m + 2, m + 1);
+            s = fabs(v0) + fabs(v1) + fabs(v2);
+            rs = fast_rcp(s);
+            v0 *= rs;
+            v1 *= rs;
+            v2 *= rs;
+            M.hiA1 = liveA ? M.hiA1 : hiA1;
+            M.loA2 = liveA ? M.loA2 : loA2;
+            M.hiB1 = liveA ? M.hiB1 : hiB1;
+            M.loB2 = liveA ? M.loB2 : loB2;
+            M.hiB2 = liveA ? M.hiB2 : hiB2;
+            M.live = liveA ? M.live : 1u;
+        }
+        {
+            const bool first = liveA ? fA : fB, last = liveA ? lA : lB;
+            qr2_iter_m<true, true, true, V>(M, t, j, first, last, two, v0, v1, v2);
+            const bool park = last;
+            M.hiA1 = park ? -kNever : M.hiA1;
+            M.loA2 = park ? kNever : M.loA2;
+            M.hiB1 = park ? -kNever : M.hiB1;
+            M.loB2 = park ? kNever : M.loB2;
+            M.hiB2 = park ? -kNever : M.hiB2;
+            M.live = park ? 0u : M.live;
+        }
+        ++t;
+    }
+}
+
 // One sweep over the window [l, i] from start row m with start vector (v0, v1, v2); (rt1r, rt1i, rt2r, rt2i) are the
 // shifts, needed again for the trailing bulge's start vector.
 template <class V>
@@ -924,6 +1184,12 @@ __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, 
 #endif
                                           ) {
     QRP(long long tp = qr_now();)
+#ifndef EGS_QR2_NO_MERGE
+    if (i - l >= 32 && i - l <= 58) {                       // window of 33 .. 59 rows: two sub-passes per iteration
+        qr2_sweep_m<V>(H, l, i, m, lane, v0, v1, v2, rt1r, rt1i, rt2r, rt2i);
+        return;
+    }
+#endif
     constexpr int SR = V::kSR, SC = V::kSC;
     const int g = lane >> 5, j = lane & 31;
     const bool two = (m == l);
