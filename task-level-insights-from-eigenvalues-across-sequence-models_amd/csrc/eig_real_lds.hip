@@ -1178,18 +1178,21 @@ __device__ __forceinline__ void qr2_sweep_m(const V& H, const int l, const int i
 template <class V>
 __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, const int m, const int lane, double v0,
                                           double v1, double v2, const double rt1r, const double rt1i, const double rt2r,
-                                          const double rt2i
+                                          const double rt2i, const int no_merge
 #ifdef EGS_QR_PROF
                                           , QrProf& P
 #endif
                                           ) {
     QRP(long long tp = qr_now();)
-#ifndef EGS_QR2_NO_MERGE
-    if (i - l >= 32 && i - l <= 58) {                       // window of 33 .. 59 rows: two sub-passes per iteration
+#ifndef EGS_QR2_MERGE_KN
+#define EGS_QR2_MERGE_KN 0
+#endif
+    // window of 33 .. 59 rows: two sub-passes per iteration (EGS_QR2_NO_MERGE=1 at launch: the three-pass form, A/B and
+    // the bit-identity test)
+    if (V::kN >= EGS_QR2_MERGE_KN && !no_merge && i - l >= 32 && i - l <= 58) {
         qr2_sweep_m<V>(H, l, i, m, lane, v0, v1, v2, rt1r, rt1i, rt2r, rt2i);
         return;
     }
-#endif
     constexpr int SR = V::kSR, SC = V::kSC;
     const int g = lane >> 5, j = lane & 31;
     const bool two = (m == l);
@@ -1303,7 +1306,7 @@ __device__ __forceinline__ void qr2_sweep(const V& H, const int l, const int i, 
 template <class V>
 __device__ __forceinline__ int hqr_wave(const V H, const int n, const int lane, double* __restrict__ w_out,
                                         int32_t* __restrict__ info_out, const double rescale, const int stop_below = 0,
-                                        const int n_it = 0) {
+                                        const int n_it = 0, const int no_merge = 0) {
     const double ulp = 2.220446049250313e-16;                      // dlamch('P')
     const double safmin = 2.2250738585072014e-308;
     // n = 64 layouts: the matrix was scaled to max |entry| in [1, 2), so a sub-diagonal entry below 1e-200 is negligible
@@ -1573,10 +1576,10 @@ __device__ __forceinline__ int hqr_wave(const V H, const int n, const int lane, 
             if constexpr (V::kFast) {
 #ifdef EGS_QR_PROF
                 { const long long n_ = qr_now(); P.scan += n_ - tscan; P.nsweep += 1; }
-                qr2_sweep(H, l, i, m, lane, v0, v1, v2, rt1r, rt1i, rt2r, rt2i, P);
+                qr2_sweep(H, l, i, m, lane, v0, v1, v2, rt1r, rt1i, rt2r, rt2i, no_merge, P);
                 tscan = qr_now();
 #else
-                qr2_sweep(H, l, i, m, lane, v0, v1, v2, rt1r, rt1i, rt2r, rt2i);
+                qr2_sweep(H, l, i, m, lane, v0, v1, v2, rt1r, rt1i, rt2r, rt2i, no_merge);
 #endif
             } else
 #endif
@@ -1638,7 +1641,7 @@ __host__ __device__ inline int hqr_pair_ld(int n) {
 template <class V>
 __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ src, int n, int lane,
                                         double* __restrict__ wo, int32_t* __restrict__ info, double rescale,
-                                        const bool normalise) {
+                                        const bool normalise, const int no_merge) {
     // load the Hessenberg part plus the two extra sub-diagonals a bulge may touch (zeros); 8 rows of global loads in
     // flight at a time, always from valid addresses (clamped lane), zeroed / dropped by value afterwards
     const int lcl = (lane < n) ? lane : n - 1;
@@ -1681,7 +1684,7 @@ __device__ __forceinline__ void hqr_run(const V H, const double* __restrict__ sr
             }
         }
     }
-    hqr_wave(H, n, lane, wo, info, rescale);
+    hqr_wave(H, n, lane, wo, info, rescale, 0, 0, no_merge);
 }
 
 // N64 = true: n == 64, only the two compile-time layouts (two-bulge sweep); false: any n < 64 (run-time leading dimension,
@@ -1694,7 +1697,7 @@ template <bool N64>
 __global__ __launch_bounds__(512, EGS_HQR_MIN_WAVES_PER_EU) void hqr_real_kernel(const double* __restrict__ hin, int64_t nmat, int n,
                                                        double* __restrict__ w, int32_t* __restrict__ info,
                                                        int waves_per_block, int scaled,
-                                                       unsigned long long* __restrict__ next_mat) {
+                                                       unsigned long long* __restrict__ next_mat, int no_merge) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -1719,11 +1722,11 @@ __global__ __launch_bounds__(512, EGS_HQR_MIN_WAVES_PER_EU) void hqr_real_kernel
         } else {
         const double rescale = scaled ? scalbn(1.0, info[mat]) : 1.0;
         if constexpr (N64) {
-            if ((wave & 1) == 0) hqr_run(MatViewT<kLd64, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale, !scaled);
-            else hqr_run(MatViewT<kLd64, true>{base, ldp}, src, n, lane, wo, info + mat, rescale, !scaled);
+            if ((wave & 1) == 0) hqr_run(MatViewT<kLd64, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale, !scaled, no_merge);
+            else hqr_run(MatViewT<kLd64, true>{base, ldp}, src, n, lane, wo, info + mat, rescale, !scaled, no_merge);
         } else {
-            if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale, false);
-            else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat, rescale, false);
+            if ((wave & 1) == 0) hqr_run(MatViewT<0, false>{base + 7, ldp}, src, n, lane, wo, info + mat, rescale, false, no_merge);
+            else hqr_run(MatViewT<0, true>{base, ldp}, src, n, lane, wo, info + mat, rescale, false, no_merge);
         }
         }
         wave_lds_sync();                                          // this matrix's LDS traffic is complete before the next load
@@ -1808,7 +1811,8 @@ __device__ __forceinline__ void tail_handoff_read(const V H, const int rem, cons
 
 __global__ __launch_bounds__(kTailWaves* kWave, 4) void hqr_tail_kernel(const double* __restrict__ handoff, int64_t nmat,
                                                                          double* __restrict__ w, int32_t* __restrict__ info,
-                                                                         unsigned long long* __restrict__ next_mat) {
+                                                                         unsigned long long* __restrict__ next_mat,
+                                                                         int no_merge) {
     extern __shared__ __attribute__((aligned(16))) double smem_tail[];
     const int lane0 = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -1828,12 +1832,12 @@ __global__ __launch_bounds__(kTailWaves* kWave, 4) void hqr_tail_kernel(const do
                 const MatViewT<kTailLd, false, kTailN> H{base + 7, kTailLd};
                 tail_handoff_read(H, rem, rec, lane);
                 wave_lds_sync();
-                hqr_wave(H, rem, lane, wo, info + mat, rescale, 0, 64);
+                hqr_wave(H, rem, lane, wo, info + mat, rescale, 0, 64, no_merge);
             } else {
                 const MatViewT<kTailLd, true, kTailN> H{base, kTailLd};
                 tail_handoff_read(H, rem, rec, lane);
                 wave_lds_sync();
-                hqr_wave(H, rem, lane, wo, info + mat, rescale, 0, 64);
+                hqr_wave(H, rem, lane, wo, info + mat, rescale, 0, 64, no_merge);
             }
         }
         wave_lds_sync();
@@ -1861,7 +1865,7 @@ __device__ __forceinline__ void store_hessenberg(const V H, const double (&A)[16
 __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
     const double* __restrict__ a, int64_t nmat, int lda, int64_t stride, double* __restrict__ w,
     int32_t* __restrict__ info, double* __restrict__ scratch, int balance, unsigned long long* __restrict__ next_mat,
-    double* __restrict__ handoff) {
+    double* __restrict__ handoff, int no_merge) {
     extern __shared__ __attribute__((aligned(16))) double smem_fused[];
     constexpr int n = 64, ldp = kLd64;
     const int lane0 = threadIdx.x & (kWave - 1);
@@ -1899,13 +1903,13 @@ __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
                 const MatViewT<kLd64, false> H{base + 7, ldp};
                 store_hessenberg(H, A, L);
                 wave_lds_sync();
-                const int rem = hqr_wave(H, n, lane, wo, info + mat, rescale, stop_below);
+                const int rem = hqr_wave(H, n, lane, wo, info + mat, rescale, stop_below, 0, no_merge);
                 if (handoff != nullptr) tail_handoff_write(H, rem, e, handoff + mat * (int64_t)kTailRec, lane);
             } else {
                 const MatViewT<kLd64, true> H{base, ldp};
                 store_hessenberg(H, A, L);
                 wave_lds_sync();
-                const int rem = hqr_wave(H, n, lane, wo, info + mat, rescale, stop_below);
+                const int rem = hqr_wave(H, n, lane, wo, info + mat, rescale, stop_below, 0, no_merge);
                 if (handoff != nullptr) tail_handoff_write(H, rem, e, handoff + mat * (int64_t)kTailRec, lane);
             }
         }
@@ -1977,6 +1981,9 @@ int hess_real_launch(const double* a, int64_t nmat, int n, int lda, int64_t stri
     return 0;
 }
 
+// A/B switch, read at launch: the three-pass n = 64 sweep instead of the merged two-pass one (bit-identical results)
+static int qr2_no_merge() { return getenv("EGS_QR2_NO_MERGE") ? 1 : 0; }
+
 int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* info, int scaled, hipStream_t stream,
                     unsigned long long* queue) {
     if (nmat == 0 || n == 0) return 0;
@@ -2016,10 +2023,10 @@ int hqr_real_launch(const double* h, int64_t nmat, int n, double* w, int32_t* in
     }
     if (n == 64)
         hipLaunchKernelGGL(hqr_real_kernel<true>, dim3(gq), dim3(hqr_waves * kWave), hqr_lds, stream, h, nmat, n, w, info,
-                           hqr_waves, scaled, queue);
+                           hqr_waves, scaled, queue, qr2_no_merge());
     else
         hipLaunchKernelGGL(hqr_real_kernel<false>, dim3(gq), dim3(hqr_waves * kWave), hqr_lds, stream, h, nmat, n, w, info,
-                           hqr_waves, scaled, queue);
+                           hqr_waves, scaled, queue, 0);
     EGS_LAUNCH_CHECK();
     return 0;
 }
@@ -2063,10 +2070,10 @@ int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t s
                 EGS_HIP(hipMemsetAsync(queues, 0, 2 * sizeof(unsigned long long), stream));
                 hipLaunchKernelGGL(eig_real64_kernel, dim3((unsigned)blocks), dim3(kFusedWaves * kWave), kFusedLds, stream,
                                    a + m0 * stride, cnt, lda, stride, w + m0 * 2 * (int64_t)n, info + m0, hws, balance,
-                                   queues, hand);
+                                   queues, hand, qr2_no_merge());
                 EGS_LAUNCH_CHECK();
                 hipLaunchKernelGGL(hqr_tail_kernel, dim3((unsigned)tblocks), dim3(kTailWaves * kWave), kTailLds, stream,
-                                   hand, cnt, w + m0 * 2 * (int64_t)n, info + m0, queues + 1);
+                                   hand, cnt, w + m0 * 2 * (int64_t)n, info + m0, queues + 1, qr2_no_merge());
                 EGS_LAUNCH_CHECK();
             }
             return 0;
@@ -2083,7 +2090,7 @@ int eig_real_lds_launch(const double* a, int64_t nmat, int n, int lda, int64_t s
             EGS_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream));
         }
         hipLaunchKernelGGL(eig_real64_kernel, dim3((unsigned)blocks), dim3(kFusedWaves * kWave), kFusedLds, stream, a, nmat,
-                           lda, stride, w, info, hws, balance, queue, static_cast<double*>(nullptr));
+                           lda, stride, w, info, hws, balance, queue, static_cast<double*>(nullptr), qr2_no_merge());
         EGS_LAUNCH_CHECK();
         return 0;
     }

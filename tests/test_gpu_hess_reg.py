@@ -375,3 +375,31 @@ def test_workspace_falls_back_to_passes_under_memory_pressure(gpu_ops, monkeypat
     assert len(calls) >= 2 and int(info.abs().sum().item()) == 0
     assert torch.equal(torch.view_as_real(w), torch.view_as_real(w_ref))      # passes do not change a bit
     gpu_ops.release_workspaces()
+
+
+def test_merged_two_pass_sweep_is_bit_identical_to_the_three_pass_sweep(gpu_ops, monkeypatch):
+    """Round 4: for windows of 33 .. 59 rows an iteration of the n = 64 sweep runs two sub-passes (moving column /
+    bottom-row primaries) instead of three.  Every element receives the same operations in the same order, so spectra and
+    info agree with the three-pass form (EGS_QR2_NO_MERGE=1) to the last bit -- on Gaussian and benchmark-style matrices,
+    Hessenberg input, reducible matrices (sweeps that start below the top of the window: one bulge) and skew-symmetric
+    ones (the tiny-column path), in the two-phase, one-kernel and two-kernel forms of the solver."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2026)
+    rnd = lambda n: torch.randn((n, 64, 64), generator=g, device="cuda", dtype=torch.float64)
+    blk = rnd(1500) / 8
+    blk[:, 40:, :40] = 0.0
+    sk = rnd(1500)
+    a = torch.cat([rnd(3000) / 8, torch.triu(rnd(1500), -1), blk, sk - sk.transpose(1, 2),
+                   rnd(1500) * torch.logspace(-3, 3, 64, device="cuda", dtype=torch.float64)[None, :, None]])
+    for form in ({}, {"EGS_EIG_ONE_PHASE": "1"}, {"EGS_EIG_UNFUSED": "1"}):
+        for k, v in form.items():
+            monkeypatch.setenv(k, v)
+        w, info = gpu_ops.eig_general_batched(a)
+        monkeypatch.setenv("EGS_QR2_NO_MERGE", "1")
+        w3, info3 = gpu_ops.eig_general_batched(a)
+        monkeypatch.delenv("EGS_QR2_NO_MERGE")
+        for k in form:
+            monkeypatch.delenv(k)
+        assert torch.equal(info, info3) and int(info.abs().sum().item()) == 0, form
+        assert torch.equal(torch.view_as_real(w), torch.view_as_real(w3)), form
+    assert O.max_abs_dlambda(w[:64].cpu().numpy(), np.linalg.eigvals(a[:64].cpu().numpy())) < 1e-11

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Bit-identity of the merged two-pass n = 64 sweep (round 4) with the three-pass one: the same batch through the working
-tree's library and through a -DEGS_QR2_NO_MERGE build (tools/build_variant.sh nomerge -DEGS_QR2_NO_MERGE); every element
-receives the same operations in the same order, so spectra and info must agree to the last bit.
-    python tools/check_merge.py dump out.pt     (EGS_LIB_PATH selects the library)
+"""Bit-identity of the merged two-pass n = 64 sweep (round 4) with the three-pass one (EGS_QR2_NO_MERGE=1 at launch): every
+element receives the same operations in the same order, so spectra and info must agree to the last bit.
+    python tools/check_merge.py dump out.pt     (EGS_LIB_PATH / EGS_QR2_NO_MERGE select library and form)
     python tools/check_merge.py cmp a.pt b.pt"""
 import importlib, os, sys
 import numpy as np, torch
