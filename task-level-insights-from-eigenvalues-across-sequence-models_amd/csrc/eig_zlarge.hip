@@ -1178,6 +1178,7 @@ __device__ __forceinline__ void zapply_u(zq* __restrict__ H, int n, zq* __restri
             }
         }
         const v4d dr = k1 - k3, di = k1 + k2;
+#ifdef EGS_ZAPPLY_VIA_LDS
         __syncthreads();
         if (tact) {
 #pragma unroll
@@ -1195,6 +1196,25 @@ __device__ __forceinline__ void zapply_u(zq* __restrict__ H, int n, zq* __restri
             }
         }
         __syncthreads();
+#else
+        // Round 4: the result tile goes from the accumulators straight to memory.  Register q of lane (cl, kk) holds
+        // out(f = 16 ft + kk + 4 q, g = 16 gt + cl): per store instruction the four kk lanes of a column write 64
+        // contiguous bytes (LEFT = false: f runs along a column of H) or the sixteen cl lanes 256 (LEFT = true: g does) --
+        // good enough for 64 KB per chunk, and the transposition through the window array with its two barriers (and
+        // 1,100 LDS cycles) per chunk is gone.
+        if (tact) {
+            const int g = gt * 16 + cl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = ft * 16 + kk + 4 * q;
+                if (f < nfc && g < wd) {
+                    const int64_t ad = LEFT ? ((int64_t)(fbase + f) * n + (s + g)) : ((int64_t)(s + g) * n + (fbase + f));
+                    H[ad] = {dr[q], di[q]};
+                }
+            }
+        }
+        __syncthreads();                                              // every wave has read X: the next chunk may be staged
+#endif
     }
 }
 
