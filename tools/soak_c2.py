@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak of the n = 64 real solver: many full-size batches of random matrices of several kinds; every spectrum must be
 flagged converged, sum to the trace and lie inside the Frobenius ball.  One line per kind.
-    BATCHES=8 python tools/soak_c2.py"""
+    BATCHES=8 python tools/soak_c2.py
+CMP_NO_MERGE=1 (n = 64): every batch is also solved with the three-pass sweep (EGS_QR2_NO_MERGE=1) and the two spectra
+must agree bit for bit (round 4: merged two-pass iterations)."""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,6 +29,13 @@ for name, make in kinds.items():
     for b in range(nb):
         a = make()
         w, info = ops.eig_general_batched(a)
+        if os.environ.get("CMP_NO_MERGE"):
+            os.environ["EGS_QR2_NO_MERGE"] = "1"
+            w3, info3 = ops.eig_general_batched(a)
+            del os.environ["EGS_QR2_NO_MERGE"]
+            if not (torch.equal(torch.view_as_real(w), torch.view_as_real(w3)) and torch.equal(info, info3)):
+                bad += int((torch.view_as_real(w) != torch.view_as_real(w3)).any(dim=-1).any(dim=-1).sum().item()) + 1
+            del w3, info3
         bad += int((info != 0).sum().item())
         fro = torch.linalg.matrix_norm(a)
         tr = max(tr, float(((w.sum(dim=1) - a.diagonal(dim1=1, dim2=2).sum(dim=1)).abs() / fro).max().item()))
