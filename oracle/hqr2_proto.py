@@ -22,6 +22,7 @@ from .hqr_proto import ULP, SAFMIN, lanv2
 
 DIST = 4
 EXACT_ZEROS = False
+E44_MIN_WINDOW = 44
 
 
 def charpoly4(h):
@@ -182,8 +183,8 @@ def hqr2_eigvals(hin, shifts="e44", stats=None, nb=2):
                     rr = r1 if abs(r1 - d) <= abs(r2 - d) else r2
                     sA, pA = 2.0 * rr, rr * rr
                 sB, pB = sA, pA
-                # "e44hi" (model runs): the 4 x 4 shifts only while the window still ends at row 44 or later
-                if (shifts == "e44" or (shifts == "e44hi" and i >= 44)) and i - l + 1 >= 6:
+                # "e44hi" (model runs): the 4 x 4 shifts only in windows of more than E44_MIN_WINDOW rows
+                if (shifts == "e44" or (shifts == "e44hi" and i - l >= E44_MIN_WINDOW)) and i - l + 1 >= 6:
                     blk = h[i - 3:i + 1, i - 3:i + 1]
                     sc = float(np.abs(blk).sum())
                     if sc > 0.0:
@@ -218,6 +219,8 @@ def hqr2_eigvals(hin, shifts="e44", stats=None, nb=2):
                 b.s, b.p = s_, p_
                 bl.append(b)
             nit = (i - 1 - m) + 1 + (0 if single else DIST * (nb - 1))
+            if stats is not None and "log" in stats:
+                stats["log"].append((l, i, m, nit))          # one record per sweep (cost models weight by window length)
             for t in range(nit):
                 iters_total += 1
                 act = []
