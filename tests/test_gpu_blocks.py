@@ -449,3 +449,23 @@ def test_ssd_dt_limit_clamps_decay_and_input_scale(pkg, gpu_ops):
         yb = b.out_proj(b._scan(x, torch.exp(dtc * -torch.exp(b.A_log.float())), dtc, Bm, Cm))
     assert (dt.float() != dtc).any()                       # the limit is active on this input
     torch.testing.assert_close(ya, yb, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_softmax_attention_more_units_than_resident_workgroups(gpu_ops):
+    """Round 4: the flash-forward kernel runs a resident grid that strides over (sequence-head, tile pair) units.  With
+    3,000 units every workgroup takes several: each sequence's result must not depend on which other sequences share the
+    launch (bit for bit: the two halves of the batch run alone give the same values), and a sample of sequences -- first,
+    last, middle -- must match the oracle."""
+    rng = np.random.default_rng(44)
+    B, L, H, hd, dv = 300, 520, 2, 32, 32                     # T = 9 tiles (odd: the middle tile pairs with itself)
+    qk = rng.standard_normal((B, L, 2, H, hd)).astype(np.float32)
+    v = rng.standard_normal((B, L, H, dv)).astype(np.float32)
+    t, tv = dev(qk), dev(v.reshape(B, L, H * dv))
+    full = gpu_ops.softmax_attention_fwd(t[:, :, 0], t[:, :, 1], tv)
+    lo = gpu_ops.softmax_attention_fwd(t[:150, :, 0], t[:150, :, 1], tv[:150])
+    hi = gpu_ops.softmax_attention_fwd(t[150:, :, 0], t[150:, :, 1], tv[150:])
+    assert torch.equal(full[:150], lo) and torch.equal(full[150:], hi)
+    pick = [0, 1, 149, 150, 298, 299]
+    want = BO.softmax_attention(qk[pick], v[pick])
+    close(full[pick].reshape(len(pick), L, H, dv), want, rtol=2e-5)

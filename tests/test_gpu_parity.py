@@ -759,3 +759,25 @@ def test_softmax_one_pass_kernel_on_adversarial_score_profiles(gpu_ops, kind):
     err_hip = np.max(np.abs(got[ok] - exact[ok]) / np.abs(exact[ok]))
     assert err_ref < 1e-3, err_ref
     assert err_hip <= 2.0 * err_ref + 1e-6, (err_hip, err_ref)       # 1e-6: the fp32 exponential's own floor (3e-7)
+
+
+@pytest.mark.gpu
+def test_softmax_eta_more_units_than_resident_workgroups(gpu_ops):
+    """Round 4: K4's row-statistics kernel runs a resident grid striding over (sequence-head, tile pair) units.  With
+    4,800 units every workgroup takes several: eta of a sequence must not depend on the rest of the batch (bit for bit
+    against the two halves run alone), and first / middle / last sequences must match the oracle."""
+    rng = np.random.default_rng(45)
+    B, L, D, d_qk, H = 600, 512, 32, 32, 2
+    x = rng.standard_normal((B, L, D)).astype(np.float32)
+    w = (rng.standard_normal((2 * d_qk + D, D)) / np.sqrt(D)).astype(np.float32)
+    b = (rng.standard_normal(2 * d_qk + D) * 0.1).astype(np.float32)
+    tx, tw, tb = dev(x), dev(w[:2 * d_qk]), dev(b[:2 * d_qk])
+    full = gpu_ops.softmax_eta(tx, tw, tb, d_qk, H)
+    lo = gpu_ops.softmax_eta(tx[:300], tw, tb, d_qk, H)
+    hi = gpu_ops.softmax_eta(tx[300:], tw, tb, d_qk, H)
+    assert torch.equal(full[:300], lo) and torch.equal(full[300:], hi)
+    pick = [0, 1, 299, 300, 598, 599]
+    want = O.eta_softmax(x[pick], w, b, d_qk, H, D)[..., 0]
+    got = full[pick].cpu().numpy()
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-5 * scale
