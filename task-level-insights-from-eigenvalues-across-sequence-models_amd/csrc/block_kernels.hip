@@ -357,7 +357,7 @@ __global__ __launch_bounds__(RS * 64) void linrec_kernel(const float* __restrict
 // two barriers.  elu+1 and the k scale are applied while staging -- no pre-pass, no workspace.
 // ---------------------------------------------------------------------------------------------------
 template <int J>
-__global__ __launch_bounds__(256) void linattn_chunk_mfma_kernel(
+__global__ __launch_bounds__(256, 2) void linattn_chunk_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t bs, int64_t ts, int64_t gs,
     const float* __restrict__ v, int64_t v_bs, int64_t v_ts, const float* __restrict__ w_ext, float* __restrict__ y,
     int64_t L, int channels, int groups, int cpg, int d, int phi, float kscale, int normalise) {
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_kernel(const float* __re
 // them with 4 lane shuffles per block.
 // ---------------------------------------------------------------------------------------------------
 template <int J, int NT>
-__global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
+__global__ __launch_bounds__(256, 2) void softmax_attn_fwd_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t qk_bs, int64_t qk_ts, int64_t qk_hs,
     const float* __restrict__ v, int64_t v_bs, int64_t v_ts, float* __restrict__ out, int64_t nbatch, int64_t seqlen,
     int num_heads, int hd, int dv, float scale) {
@@ -1254,17 +1254,17 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
     const int64_t s_end = (t0 + 64 < seqlen) ? t0 + 64 : seqlen;
 
     float4 kpre[kK4], vpre[kV4];
-    auto fetch = [&](int64_t s0) {
+    auto fetch = [&](int64_t s0, int tq) {
 #pragma unroll
         for (int x = 0; x < kK4; ++x) {
-            const int idx = tid + 256 * x;
+            const int idx = tq + 256 * x;
             const int sr = idx / J, j = idx - sr * J;
             const int64_t sk = (s0 + sr < seqlen) ? s0 + sr : seqlen - 1;
             kpre[x] = *reinterpret_cast<const float4*>(kbase + sk * qk_ts + ((4 * j < hd) ? 4 * j : hd - 4));
         }
 #pragma unroll
         for (int x = 0; x < kV4; ++x) {
-            const int idx = tid + 256 * x;
+            const int idx = tq + 256 * x;
             const int sr = idx / (NT * 4), j = idx - sr * (NT * 4);
             const int64_t sk = (s0 + sr < seqlen) ? s0 + sr : seqlen - 1;
             const float* src = vbase + sk * v_ts;
@@ -1274,7 +1274,6 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
             vpre[x] = make_float4(e[0], e[1], e[2], e[3]);
         }
     };
-    fetch(0);
 
     float m_run = -INFINITY, l_run = 0.0f;
     f32x4 o[NT];
@@ -1282,10 +1281,15 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
     for (int nt = 0; nt < NT; ++nt) o[nt] = {0.0f, 0.0f, 0.0f, 0.0f};
 
     for (int64_t s0 = 0; s0 < s_end; s0 += 64) {
+        // Staging indices are derived from an opaque copy of the thread index inside the loop: hoisted out of it they would
+        // stay live (spilled) across the matrix-core section, which needs the registers for 2 waves per SIMD.
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        fetch(s0, tq);                                                // (in flight while the other waves finish the block)
         __syncthreads();                                              // previous block fully consumed
 #pragma unroll
         for (int x = 0; x < kK4; ++x) {
-            const int idx = tid + 256 * x;
+            const int idx = tq + 256 * x;
             const int sr = idx / J, j = idx - sr * J;
             const bool ok = (4 * j < hd) && (s0 + sr < seqlen);
             ks2[(0 * 64 + sr) * kLd + j] = ok ? kpre[x].x : 0.0f;
@@ -1295,7 +1299,7 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
         }
 #pragma unroll
         for (int x = 0; x < kV4; ++x) {
-            const int idx = tid + 256 * x;
+            const int idx = tq + 256 * x;
             const int sr = idx / (NT * 4), j = idx - sr * (NT * 4);
             const bool rok = s0 + sr < seqlen;
             float4 val = vpre[x];
@@ -1306,7 +1310,6 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_mfma_kernel(
             *reinterpret_cast<float4*>(vs + sr * kLv + 4 * j) = val;
         }
         __syncthreads();
-        fetch((s0 + 64 < s_end) ? s0 + 64 : 0);
         if (s0 > wave_tmax) continue;                                 // wave-uniform: whole block above this wave's rows
 
         f32x4 acc[4];
