@@ -23,6 +23,7 @@
 // The elementwise q/k preparation (elu+1, scale, zero padding to the register tile) is a separate streaming pass into a
 // compact record stream [B][G][RS][L][q | k][DR] -- one contiguous record per (wave, token); w_t of linear attention
 // comes from a lane-per-token prefix pass over that stream.
+#include <type_traits>
 #include <stdlib.h>
 
 #include "egs_common.h"
@@ -1312,69 +1313,85 @@ __global__ __launch_bounds__(256, 2) void softmax_attn_fwd_mfma_kernel(
         __syncthreads();
         if (s0 > wave_tmax) continue;                                 // wave-uniform: whole block above this wave's rows
 
-        f32x4 acc[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) acc[x] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float* kr = ks2 + (g * 64 + c) * kLd;
-#pragma unroll
-        for (int jj = 0; jj < J; jj += 4) {
-            float4 k4[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) k4[x] = *reinterpret_cast<const float4*>(kr + 16 * x * kLd + jj);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].x, qreg[jj], acc[x], 0, 0, 0);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].y, qreg[jj + 1], acc[x], 0, 0, 0);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].z, qreg[jj + 2], acc[x], 0, 0, 0);
-#pragma unroll
-            for (int x = 0; x < 4; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].w, qreg[jj + 3], acc[x], 0, 0, 0);
-        }
-        // online softmax for row t (this lane's 16 of the block's 64 keys; the other 48 sit in the other lane groups)
-        float p[4][4];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float sc[4] = {acc[x].x, acc[x].y, acc[x].z, acc[x].w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t sidx = s0 + 16 * x + 4 * g + r;
-                const bool ok = sidx <= t && sidx < seqlen;
-                p[x][r] = ok ? sc[r] : -INFINITY;
-                mx = fmaxf(mx, p[x][r]);
+        // Key tiles of 16: a block below the diagonal needs all four; in the diagonal block (s0 == t0) wave w's rows end at
+        // key 16 w + 15, so tiles x > w are fully masked -- one instantiation of the body per tile count (run-time guards
+        // around the interleaved MFMAs measured slower: profiles/r04_variants.md).
+        auto block_body = [&](auto nx_tag) {
+            constexpr int NX = decltype(nx_tag)::value;
+            f32x4 acc[NX];
+    #pragma unroll
+            for (int x = 0; x < NX; ++x) acc[x] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float* kr = ks2 + (g * 64 + c) * kLd;
+    #pragma unroll
+            for (int jj = 0; jj < J; jj += 4) {
+                float4 k4[NX];
+    #pragma unroll
+                for (int x = 0; x < NX; ++x) k4[x] = *reinterpret_cast<const float4*>(kr + 16 * x * kLd + jj);
+    #pragma unroll
+                for (int x = 0; x < NX; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].x, qreg[jj], acc[x], 0, 0, 0);
+    #pragma unroll
+                for (int x = 0; x < NX; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].y, qreg[jj + 1], acc[x], 0, 0, 0);
+    #pragma unroll
+                for (int x = 0; x < NX; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].z, qreg[jj + 2], acc[x], 0, 0, 0);
+    #pragma unroll
+                for (int x = 0; x < NX; ++x) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[x].w, qreg[jj + 3], acc[x], 0, 0, 0);
             }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;      // fully masked so far (rows past the end)
-        const float corr = __expf(m_run - m_use);                     // exp(-inf) = 0 on the first block
-        float rs = 0.0f;
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[x][r] = __expf(p[x][r] - m_use);
-                rs += p[x][r];
+            // online softmax for row t (this lane's 16 of the block's 64 keys; the other 48 sit in the other lane groups)
+            float p[NX][4];
+            float mx = -INFINITY;
+    #pragma unroll
+            for (int x = 0; x < NX; ++x) {
+                const float sc[4] = {acc[x].x, acc[x].y, acc[x].z, acc[x].w};
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t sidx = s0 + 16 * x + 4 * g + r;
+                    const bool ok = sidx <= t && sidx < seqlen;
+                    p[x][r] = ok ? sc[r] : -INFINITY;
+                    mx = fmaxf(mx, p[x][r]);
+                }
             }
-        l_run = l_run * corr + rs;
-        m_run = m_new;
-        // rescale the output rows 4 g + r with the factor of query row 4 g + r (held by lane 4 g + r)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float cr = __shfl(corr, 4 * g + r, 64);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) o[nt][r] *= cr;
-        }
-        // P V:  A = P^T register (x, r) -> keys 16 x + 4 g + r;  B = V[key][16 nt + c]
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-#pragma unroll
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;      // fully masked so far (rows past the end)
+            const float corr = __expf(m_run - m_use);                     // exp(-inf) = 0 on the first block
+            float rs = 0.0f;
+    #pragma unroll
+            for (int x = 0; x < NX; ++x)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[x][r] = __expf(p[x][r] - m_use);
+                    rs += p[x][r];
+                }
+            l_run = l_run * corr + rs;
+            m_run = m_new;
+            // rescale the output rows 4 g + r with the factor of query row 4 g + r (held by lane 4 g + r)
+    #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float* vr = vs + (16 * x + 4 * g + r) * kLv + c;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[x][r], vr[16 * nt], o[nt], 0, 0, 0);
+                const float cr = __shfl(corr, 4 * g + r, 64);
+    #pragma unroll
+                for (int nt = 0; nt < NT; ++nt) o[nt][r] *= cr;
+            }
+            // P V:  A = P^T register (x, r) -> keys 16 x + 4 g + r;  B = V[key][16 nt + c]
+    #pragma unroll
+            for (int x = 0; x < NX; ++x) {
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* vr = vs + (16 * x + 4 * g + r) * kLv + c;
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[x][r], vr[16 * nt], o[nt], 0, 0, 0);
+                }
+            }
+        };
+        if (s0 < t0) {
+            block_body(std::integral_constant<int, 4>{});
+        } else {
+            switch (__builtin_amdgcn_readfirstlane(w)) {
+                case 0: block_body(std::integral_constant<int, 1>{}); break;
+                case 1: block_body(std::integral_constant<int, 2>{}); break;
+                case 2: block_body(std::integral_constant<int, 3>{}); break;
+                default: block_body(std::integral_constant<int, 4>{}); break;
             }
         }
     }
