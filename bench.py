@@ -433,7 +433,7 @@ def stream_rooflines(ops, device):
                 "workload": "C4 / 8 GPUs block forward: causal linear attention, B=512, L=4096, d_qk=128, 128 channels",
                 "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "ms": ms,
                 "note": "fp32 MFMA, chunked recurrence; algorithmic flops = 4 d C per token (state update + readout); "
-                        "the kernel executes 1.4x that (intra-chunk tiles), matrix pipe 83 % busy (profiles/r01_blocks.json)"})
+                        "the kernel executes 1.6x that (intra-chunk tiles; every wave recomputes the 16 x 16 score tile), matrix pipe 67 % busy at two waves per SIMD (round 4: __launch_bounds__(256, 2); profiles/r04_blocks_pmc_counters.json)"})
     del qk, v
     # K5 at config C5: 768 HiPPO-DPLR 256 x 256 complex128 matrices (6 layers x 128 feature columns, per-column steps):
     # fused DPLR build, blocked Hessenberg on the fp64 matrix cores, windowed multishift QR -- the two stages timed apart
