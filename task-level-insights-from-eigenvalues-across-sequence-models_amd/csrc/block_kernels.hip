@@ -1205,8 +1205,10 @@ __global__ __launch_bounds__(256) void softmax_attn_fwd_kernel(const float* __re
 // The output accumulators are in the D layout (row 4 (l/16) + r, column l % 16); the per-row rescale factors reach
 // them with 4 lane shuffles per block.
 // ---------------------------------------------------------------------------------------------------
+// (two workgroups per CU up to head_dim 128; head_dim 256 keeps q alone in 64 registers and runs one wave per SIMD without
+// scratch -- with the two-wave limit it spilled 298 registers and took 4.0 instead of 1.74 ms at 64 x 1024 x 2 heads)
 template <int J, int NT>
-__global__ __launch_bounds__(256, 2) void softmax_attn_fwd_mfma_kernel(
+__global__ __launch_bounds__(256, (J <= 32 ? 2 : 1)) void softmax_attn_fwd_mfma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t qk_bs, int64_t qk_ts, int64_t qk_hs,
     const float* __restrict__ v, int64_t v_bs, int64_t v_ts, float* __restrict__ out, int64_t nbatch, int64_t seqlen,
     int num_heads, int hd, int dv, float scale) {

@@ -38,6 +38,7 @@ def main():
         ("softmax-attn MQAR 64x512 D=128 d_qk=128 H=1", 64, 512, 1, 128, 128),
         ("softmax-attn 4096x512 D=128 d_qk=128 H=1", 4096, 512, 1, 128, 128),
         ("softmax-attn 64x1024 D=512 H=8 hd=64", 64, 1024, 8, 64, 64),
+        ("softmax-attn 64x1024 D=512 H=2 hd=256", 64, 1024, 2, 256, 256),
     ]
     if len(sys.argv) > 1:
         cases = [c for c in cases if sys.argv[1] in c[0]]
