@@ -83,6 +83,13 @@ def main():
     ap.add_argument("--matrices", choices=["s5", "randn"], default="s5")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-procs", default=str(CPU_POOL_PROCS),
+                    help="processes of the pooled CPU figure: a number, or 'all' for every host core (default: one GPU's "
+                         "share of the bench box's cores)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --nmat matrices PER rank (default, the driver's run); strong: --nmat matrices in TOTAL, cut "
+                         "into contiguous per-rank slabs (dist.shard_range), plus config C4's 4096-sequence batch cut the "
+                         "same way as a secondary line")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no hot path and no GPU: only the launcher + process-group plumbing of --gpus N (gloo), for the "
                          "CPU test suite; prints a line with value = null")
@@ -107,11 +114,18 @@ def main():
     if world == 1 and not args.no_cpu and args.n == 64:
         import subprocess
         try:
-            procs = max(1, min(CPU_POOL_PROCS, os.cpu_count() or 1))
+            ncpu = os.cpu_count() or 1
+            procs = ncpu if args.cpu_procs == "all" else max(1, min(int(args.cpu_procs), ncpu))
             out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--procs", str(procs),
                                   "--seconds", str(min(args.cpu_seconds, 10.0))], capture_output=True, text=True,
                                  timeout=120)
             cpu_multi = json.loads(out.stdout.strip().splitlines()[-1])
+            # say what share of the host this is, and what a linear extrapolation to every core would be (NOT measured:
+            # the bench box gives one GPU's job 16 of its cores; `--cpu-procs all` measures it where that is allowed)
+            cpu_multi["cores_of_host"] = "%d of %d" % (procs, ncpu)
+            cpu_multi["sample"] = "%s of the host's %d cores; %s" % (procs, ncpu, cpu_multi.get("sample", ""))
+            cpu_multi["all_cores_extrapolated"] = {"value": cpu_multi["value"] * ncpu / procs, "unit": "spectra/s",
+                                                   "cores": ncpu, "how": "linear in cores from the measured pool; not a measurement"}
         except Exception as exc:            # the baseline is a courtesy figure; never fail the bench on it
             cpu_multi = {"error": repr(exc)}
     if args.rehearse_launch:
@@ -134,7 +148,16 @@ def main():
     ops, egs_dist = pkg.ops, pkg.dist
     import oracle as O
 
-    n, nmat = args.n, args.nmat
+    n = args.n
+    # weak (default, the driver's run): every rank owns --nmat matrices.  strong: --nmat is the WHOLE batch, cut into
+    # contiguous slabs exactly as eval_eig cuts an analysis batch (dist.shard_range); the gather pads to the common slab.
+    strong = args.scaling == "strong"
+    nmat_total = args.nmat if strong else args.nmat * world
+    if strong:
+        lo, hi = egs_dist.shard_range(args.nmat, rank, world)
+        nmat = hi - lo
+    else:
+        nmat = args.nmat
     gen = torch.Generator(device=device)
     gen.manual_seed(64 + rank)
     a = torch.empty((nmat, n, n), dtype=torch.float64, device=device)
@@ -162,7 +185,7 @@ def main():
         for _ in range(k):
             w, info = ops.eig_general_batched(a, workspace=workspace)
             if world > 1:
-                h = egs_dist.all_gather_slabs_async(w, world * nmat)
+                h = egs_dist.all_gather_slabs_async(w, nmat_total)
                 if pending is not None:
                     pending.wait()
                 pending = h
@@ -189,7 +212,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = nmat * world / (elapsed / args.steps)
+    value = nmat_total / (elapsed / args.steps)
+    devices = device_identities(device, rank, local_rank, world, backend)
 
     # ---- per-kernel timing (HIP events on the launch stream) for the roofline object ----
     # n = 64: the step is one launch of the fused kernel (eig_real64_kernel: Hessenberg reduction in registers + QR in
@@ -263,7 +287,10 @@ def main():
     # else is reported as traffic = null with the reason -- never a silent fall-back to an older round's number.
     traffic, traffic_src, traffic_note = kernel_traffic(kname, per_launch)
     roofline = {
-        "bound": "mfma", "kernel": kname, "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
+        # the n = 64 solver is fp64 VECTOR arithmetic on an LDS-resident matrix ("bound by fp64 VALU + LDS
+        # bandwidth + serial bulge-chase latency"); the matrix cores only add up the register-resident reduction's partial
+        # sums.  The peak it is priced against is the fp64 vector peak (= the fp64 matrix peak on MI355X).
+        "bound": "valu+lds", "kernel": kname, "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
         "note": note, "avg_launch_ms": k_ms, "launches_timed": len(fused_ms) if fused else nlaunch,
         "two_kernel_stages": stages,
@@ -277,6 +304,15 @@ def main():
         secondary = stream_rooflines(ops, device)
         if not args.no_cpu:
             headline = mqar_headline(ops, device)
+
+    # ---- SURVEY 8(d)'s second C2 set: plain N(0,1)/sqrt(n) matrices (no structure to converge on) at a quarter batch ----
+    gaussian = None
+    if rank == 0 and world == 1 and n == 64 and args.matrices == "s5":
+        gaussian = gaussian_c2(ops, device, min(nmat, 131072), n, workspace)
+    # ---- strong scaling's secondary line: config C4 (4096 sequences x 4096 tokens, D = 128) cut over the ranks ----
+    c4_strong = None
+    if strong:
+        c4_strong = c4_strong_scaling(ops, egs_dist, device, rank, world, backend)
 
     # ---- parity: GPU spectra vs the known spectrum and vs LAPACK on a sample ----
     info_bad = int((info != 0).sum().item())
@@ -292,11 +328,11 @@ def main():
         result = {
             "metric": "eigen-spectra/sec (batch x seq_len x d_state matrices) + max |dlambda| vs reference",
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C2: S5 d_state=64, seq_len=1024, batch=512 -> 524288 dense 64x64 fp64 matrices per GPU "
                                    "(known S5-style spectrum under a non-normal orthogonal similarity)",
-                       "d_state": n, "matrices_per_gpu": nmat, "matrix_kind": args.matrices,
+                       "d_state": n, "matrices_per_gpu": nmat, "matrices_total": nmat_total, "matrix_kind": args.matrices,
                        "parallelism": "matrix-sharded x%d, one all_gather of spectra" % world},
             "max_abs_dlambda_vs_lapack": d_lapack, "max_abs_dlambda_vs_known": d_known, "unconverged": info_bad,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_pool": cpu_multi,
@@ -304,6 +340,11 @@ def main():
             # what the process group actually looked like (so a SCALE record shows that RCCL saw N ranks on N devices)
             "world": world, "dist_backend": backend if world > 1 else None,
             "visible_devices": torch.cuda.device_count(), "device_name": torch.cuda.get_device_name(device),
+            # one entry per rank (gathered over the process group): which physical device each rank drove, and the size
+            # of the communicator the collective ran on -- a SCALE record with N distinct uuids proves N GPUs took part
+            "ranks": devices, "comm_size": (dist.get_world_size() if world > 1 else 1),
+            "distinct_devices": len({d.get("uuid") or (d.get("host"), d.get("index")) for d in devices}),
+            "secondary_c2_gaussian": gaussian, "secondary_c4_strong": c4_strong,
         }
         if cpu is not None:
             result["speedup_vs_cpu_1core"] = value / cpu["value"]
@@ -312,6 +353,80 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def device_identities(device, rank, local_rank, world, backend):
+    """[{rank, local_rank, index, uuid, name, host}] for every rank, gathered over the process group (all_gather_object)."""
+    import socket
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "local_rank": local_rank, "index": device.index, "name": props.name, "host": socket.gethostname(),
+          "uuid": str(getattr(props, "uuid", "")) or None,
+          "pci_bus_id": getattr(props, "pci_bus_id", None)}
+    if world == 1:
+        return [me]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, me)
+    return out
+
+
+def gaussian_c2(ops, device, cnt, n, workspace):
+    """The solver on N(0,1)/sqrt(n) matrices (second set), HIP events on the launch stream, median of 3."""
+    import oracle as O
+    g = torch.Generator(device=device)
+    g.manual_seed(65)
+    a = torch.randn((cnt, n, n), generator=g, device=device, dtype=torch.float64) / np.sqrt(n)
+    w, info = ops.eig_general_batched(a, workspace=workspace)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    for r in range(3):
+        w, info = ops.eig_general_batched(a, workspace=workspace)
+        ev[r + 1].record()
+    torch.cuda.synchronize()
+    ms = float(np.median([ev[r].elapsed_time(ev[r + 1]) for r in range(3)]))
+    tf = (40.0 / 3.0) * n ** 3 * cnt / (ms * 1e-3) / 1e12
+    d = float(O.max_abs_dlambda(w[:256].cpu().numpy(), O.eigvals_dense(a[:256].cpu().numpy())))
+    return {"workload": "C2, second set: %d dense N(0,1)/sqrt(n) 64x64 fp64 matrices" % cnt, "kernel": N64_KERNELS,
+            "bound": "valu+lds", "ms": ms, "spectra_per_s": cnt / (ms * 1e-3), "achieved": tf, "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "unconverged": int((info != 0).sum().item()),
+            "max_abs_dlambda_vs_lapack": d}
+
+
+def c4_strong_scaling(ops, egs_dist, device, rank, world, backend):
+    """Config C4 as a strong-scaling line: linear-attention eta of 4096 sequences x 4096 tokens (D = 128, d_qk = 128,
+    H = 1), the batch cut over the ranks, ONE all-gather of eta; max over ranks of the step time."""
+    B, L, D, dqk = 4096, 4096, 128, 128
+    lo, hi = egs_dist.shard_range(B, rank, world)
+    g = torch.Generator(device=device)
+    g.manual_seed(4096 + rank)
+    x = torch.randn((hi - lo, L, D), generator=g, device=device)
+    g.manual_seed(4096)
+    w = (torch.rand((2 * dqk, D), generator=g, device=device) * 2 - 1) / np.sqrt(D)
+    b = (torch.rand((2 * dqk,), generator=g, device=device) * 2 - 1) / np.sqrt(D)
+
+    def step():
+        eta = ops.linattn_eta(x, w, b, dqk, 1)
+        return egs_dist.all_gather_slabs(eta, B) if world > 1 else eta
+    step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        full = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = (time.perf_counter() - t0) / 3
+    if world > 1:
+        tmax = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    return {"workload": "C4: linear attention eta, B=4096, L=4096, D=128, d_qk=128, H=1, batch cut over %d rank(s)" % world,
+            "scaling": "strong", "sequences_per_rank": hi - lo, "ms_per_step": el * 1e3, "eta_values_per_s": B * (L - 1) / el,
+            "sequences_per_s": B / el, "gathered_shape": list(full.shape)}
 
 
 def rehearse_launch(args, world, rank):
@@ -337,6 +452,8 @@ KERNEL_SOURCES = {      # the files a kernel is compiled from; their hash ties a
     "eig_real64_kernel": ("eig_real_lds.hip", "hess_reg.h", "egs_common.h"),
     "hqr_tail_kernel": ("eig_real_lds.hip", "egs_common.h"),
     "hqr_real_kernel": ("eig_real_lds.hip", "egs_common.h"),
+    "zhess_blocked_kernel": ("eig_zlarge.hip", "zq_common.h", "egs_common.h"),
+    "zmsqr_kernel": ("eig_zlarge.hip", "zq_common.h", "egs_common.h"),
 }
 
 
@@ -365,6 +482,23 @@ def kernel_traffic(kname, per_launch):
     if have != want:
         return None, src, "stale: measured on kernel source %s, this build is %s" % (have, want)
     return ent["hbm_bytes_per_matrix"] * per_launch, src, "PMC FETCH_SIZE x2 + WRITE_SIZE, kernel source %s" % want
+
+
+def kernel_traffic_launch(entry, base):
+    """(HBM-side bytes per launch, source, note) of a kernel listed by its full name in the newest traffic file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True)
+    if not files:
+        return None, None, "no profiles/r*_traffic.json"
+    src = "profiles/" + os.path.basename(files[0])
+    try:
+        ent = json.load(open(files[0]))["kernels"][entry]
+    except Exception:
+        return None, src, "newest traffic file does not list %s" % entry
+    want, have = kernel_source_sha(base), ent.get("source_sha")
+    if have != want:
+        return None, src, "stale: measured on kernel source %s, this build is %s" % (have, want)
+    return ent["hbm_bytes_per_launch"], src, "PMC FETCH_SIZE x2 + WRITE_SIZE (HBM + Infinity Cache side), kernel source %s" % want
 
 
 def stream_rooflines(ops, device):
@@ -465,17 +599,27 @@ def stream_rooflines(ops, device):
     tf_q = 4.0 * 10.0 * n ** 3 * h / (qr_ms * 1e-3) / 1e12
     tr = torch.diagonal(ab, dim1=1, dim2=2).sum(dim=1)
     trerr = float(((ww.sum(dim=1) - tr).abs() / torch.linalg.matrix_norm(ab)).max().item())
+    # counted HBM-side traffic of the Hessenberg stage (PMC, profiles/rNN_traffic.json; null when stale): its level-2 half
+    # re-reads the trailing matrix once per column, so the stage is MEMORY-bound -- priced against the HBM peak
+    hz_traffic, hz_src, hz_note = kernel_traffic_launch("zhess_blocked_kernel<16, 2>", "zhess_blocked_kernel")
     out.append({"kernel": "zhess_blocked_kernel<16,2> + zmsqr_kernel",
                 "workload": "C5: S4 HiPPO-DPLR d_state=256, 6 layers x 128 columns = 768 complex128 256x256 matrices",
-                "bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                "bound": "hbm (Hessenberg stage) + lds/valu behind barriers, mfma in the deferred updates (QR stage)",
+                "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
                 "ms": hs_ms + qr_ms, "spectra_per_s": h / ((hs_ms + qr_ms) * 1e-3), "unconverged": unconv,
                 "max_rel_trace_error": trerr,
-                "stages": {"zhess_blocked_kernel": {"ms": hs_ms, "achieved_tflops": tf_h, "frac": tf_h / FP64_PEAK_TFLOPS,
+                "stages": {"zhess_blocked_kernel": {"bound": "hbm", "ms": hs_ms, "achieved_tflops": tf_h,
+                                                    "frac_of_fp64_peak": tf_h / FP64_PEAK_TFLOPS,
+                                                    "traffic": hz_traffic, "traffic_source": hz_src, "traffic_note": hz_note,
+                                                    "counted_traffic_gbs": (hz_traffic / (hs_ms * 1e-3) / 1e9) if hz_traffic else None,
+                                                    "frac": (hz_traffic / (hs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if hz_traffic
+                                                    else 16.0 * n ** 3 / 3.0 * h / (hs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                     # its bound: one matrix-vector product with the trailing matrix per
                                                     # column = 16 n^3 / 3 bytes per matrix that no blocking removes
                                                     "hbm_gbs_algorithmic": 16.0 * n ** 3 / 3.0 * h / (hs_ms * 1e-3) / 1e9,
                                                     "hbm_frac": 16.0 * n ** 3 / 3.0 * h / (hs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                           "zmsqr_kernel": {"ms": qr_ms, "achieved_tflops": tf_q, "frac": tf_q / FP64_PEAK_TFLOPS}},
+                           "zmsqr_kernel": {"bound": "lds+valu (barrier-synchronous chase), mfma (deferred updates)",
+                                            "ms": qr_ms, "achieved_tflops": tf_q, "frac": tf_q / FP64_PEAK_TFLOPS}},
                 "note": "fp64 (matrix = vector peak); algorithmic flops 4 x (40/3) n^3 per matrix (Hessenberg 4 x (10/3) "
                         "n^3, QR 4 x 10 n^3); HIP events on the launch stream, median of 3"})
     return out

@@ -75,6 +75,13 @@ int egs_diag_ssm_lambda(int mode, const double* p0, const double* p1, const doub
 int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const double* p_re,
                       const double* p_im, const double* log_step, int64_t nmat, int n,
                       double* ab, egs_stream_t stream);
+/* The general form of discrete_DPLR (analysis/eval_eig.py:254-273): A = diag(Lambda) - P Q^H with separate P and Q
+ * (q_re, q_im : double[nmat, n]).  clip_lambda = 1 clips Re(Lambda) to <= -1e-4 as get_eigvals_ssm does before the call
+ * (:288); 0 takes Lambda as given, which is what discrete_DPLR itself does. */
+int egs_s4_dplr_build_pq(const double* lambda_re, const double* lambda_im, const double* p_re,
+                         const double* p_im, const double* q_re, const double* q_im,
+                         const double* log_step, int64_t nmat, int n, int clip_lambda,
+                         double* ab, egs_stream_t stream);
 
 /* ---- K5: batched dense non-symmetric eigenvalues -------------------------------------------------
  * Replaces np.linalg.eigvals (LAPACK ?geev, analysis/eval_eig.py:296), generalised from one matrix per

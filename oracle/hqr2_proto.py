@@ -113,11 +113,113 @@ def _larfg3(v0, v1, v2):
     return beta, t1, v1 * sc, v2 * sc
 
 
+def _aed_real(h, l, i, w, smlnum, stats, deflate=True):
+    """Aggressive early deflation on the trailing window of the active block [l, i] (Braman, Byers, Mathias 2002 II;
+    LAPACK dlaqr2's flow): real Schur form of the window with vectors, spike test from the bottom, undeflatable blocks
+    moved to the top (dtrexc), Hessenberg form restored by a reflector on the spike and a re-reduction, the columns of
+    the rows above the window multiplied by the accumulated V (eigenvalues only: nothing right of the window).
+    Returns (eigenvalues deflated [complex list, bottom first], shift pairs of the best-converged undeflated blocks).
+    Model code: SciPy's LAPACK does the window's Schur form, the swaps and the re-reduction -- what is counted is how
+    often and on which sizes (stats["aed_log"]), the kernel-side price is set by the caller (tools/aed64_model.py)."""
+    import scipy.linalg as sl
+    from scipy.linalg import lapack
+    jw = min(w, i - l + 1)
+    kwtop = i - jw + 1
+    s = h[kwtop, kwtop - 1] if kwtop > l else 0.0
+    T, V = sl.schur(np.triu(h[kwtop:i + 1, kwtop:i + 1], -1), output="real")
+    T = np.asfortranarray(T)
+    V = np.asfortranarray(V)
+    ns, ilst, nswap = jw, 1, 0
+    while ilst <= ns:
+        bulge = ns > 1 and T[ns - 1, ns - 2] != 0.0
+        if not bulge:
+            foo = abs(T[ns - 1, ns - 1]) or abs(s)
+            if abs(s * V[0, ns - 1]) <= max(smlnum, ULP * foo):
+                ns -= 1
+            else:
+                T, V, info = lapack.dtrexc(T, V, ns, ilst)
+                nswap += ns - ilst
+                ilst += 1
+        else:
+            foo = abs(T[ns - 1, ns - 1]) + math.sqrt(abs(T[ns - 1, ns - 2])) * math.sqrt(abs(T[ns - 2, ns - 1]))
+            if foo == 0.0:
+                foo = abs(s)
+            if max(abs(s * V[0, ns - 1]), abs(s * V[0, ns - 2])) <= max(smlnum, ULP * foo):
+                ns -= 2
+            else:
+                T, V, info = lapack.dtrexc(T, V, ns - 1, ilst)
+                nswap += 2 * (ns - 1 - ilst)
+                ilst += 2
+    nd = jw - ns
+    # eigenvalues of the window's diagonal blocks: [0, ns) undeflated (candidate shifts), [ns, jw) deflated
+    blocks = []
+    k = 0
+    while k < jw:
+        if k + 1 < jw and T[k + 1, k] != 0.0:
+            blocks.append((k, 2, lanv2(T[k, k], T[k, k + 1], T[k + 1, k], T[k + 1, k + 1])))
+            k += 2
+        else:
+            blocks.append((k, 1, (T[k, k], 0.0, T[k, k], 0.0)))
+            k += 1
+    deflated = []
+    for (k0, sz, (r1, i1, r2, i2)) in blocks:
+        if k0 >= ns:
+            deflated.append((k0, complex(r1, i1)))
+            if sz == 2:
+                deflated.append((k0 + 1, complex(r2, i2)))
+    # shift pairs (sum, product): the undeflated blocks with the smallest spike entries first; two real eigenvalues
+    # make one pair
+    cand = sorted((b for b in blocks if b[0] < ns), key=lambda b: max(abs(V[0, b[0]]), abs(V[0, b[0] + b[1] - 1])))
+    pairs, reals = [], []
+    for (k0, sz, (r1, i1, r2, i2)) in cand:
+        if sz == 2:
+            pairs.append((r1 + r2, r1 * r2 - i1 * i2))
+        else:
+            reals.append(r1)
+            if len(reals) == 2:
+                pairs.append((reals[0] + reals[1], reals[0] * reals[1]))
+                reals = []
+    if stats is not None:
+        stats.setdefault("aed_log", []).append((l, i, jw, ns if deflate else jw, nswap))
+        stats.setdefault("aed_windows", []).append(np.triu(h[kwtop:i + 1, kwtop:i + 1], -1).copy())
+    if nd == 0 or not deflate:
+        return [], pairs
+    if ns == 0:
+        s = 0.0
+    if ns > 1 and s != 0.0:
+        spike = s * V[0, :ns]
+        beta, _t1, _u1, _u2 = 0.0, 0.0, 0.0, 0.0
+        alpha = spike[0]
+        nrm = float(np.linalg.norm(spike))
+        beta = -math.copysign(nrm, alpha) if alpha != 0.0 else -nrm
+        v = spike.copy()
+        v[0] = alpha - beta
+        v /= v[0]
+        tau = (beta - alpha) / beta
+        Hh = np.eye(ns) - tau * np.outer(v, v)
+        T[:ns, :] = Hh @ T[:ns, :]
+        T[:, :ns] = T[:, :ns] @ Hh
+        V[:, :ns] = V[:, :ns] @ Hh
+        Hs, Q = sl.hessenberg(T[:ns, :ns], calc_q=True)
+        T[:ns, :ns] = Hs
+        T[:ns, ns:] = Q.T @ T[:ns, ns:]
+        V[:, :ns] = V[:, :ns] @ Q
+    if kwtop > l:
+        h[kwtop, kwtop - 1] = s * V[0, 0]
+    h[kwtop:i + 1, kwtop:i + 1] = np.triu(T, -1)
+    if kwtop > l:
+        h[l:kwtop, kwtop:i + 1] = h[l:kwtop, kwtop:i + 1] @ V
+    return deflated, pairs
+
+
 class _Bulge:
     __slots__ = ("k", "vec", "first", "s", "p")
 
 
-def hqr2_eigvals(hin, shifts="e44", stats=None, nb=2):
+def hqr2_eigvals(hin, shifts="e44", stats=None, nb=2, aed=0, aed_min=0, aed_shifts=False, nibble=14, aed_deflate=True):
+    """aed = w > 0: an early-deflation step on the trailing w rows before every sweep of a window of more than aed_min
+    rows (model runs, tools/aed64_model.py); aed_shifts: the two best-converged undeflated blocks of the window give the
+    two bulges' shift pairs; nibble: skip the sweep when at least that percentage of the window deflated (dlaqr0)."""
     h = np.array(hin, dtype=np.float64)
     n = h.shape[0]
     wr = np.zeros(n)
@@ -160,6 +262,24 @@ def hqr2_eigvals(hin, shifts="e44", stats=None, nb=2):
             if l >= i - 1:
                 converged = True
                 break
+            aed_pairs = None
+            if aed > 0 and i - l + 1 > max(aed_min, 3):
+                defl, aed_pairs = _aed_real(h, l, i, aed, smlnum, stats, aed_deflate)
+                if defl:
+                    jw_ = min(aed, i - l + 1)
+                    for (k0, z) in defl:
+                        wr[i - jw_ + 1 + k0], wi[i - jw_ + 1 + k0] = z.real, z.imag
+                    i -= len(defl)
+                    kdefl = 0
+                    if i < l:
+                        converged = None          # the window took the rest of the active block: start over above it
+                        break
+                    if len(defl) * 100 >= nibble * jw_ or i - l + 1 < 3:
+                        continue                  # re-scan (and try the window again) before spending a sweep
+                    if not aed_shifts:
+                        aed_pairs = None
+                if l >= i - 1:
+                    continue
             kdefl += 1
             # ---- shift pairs (sum, product) of the two bulges ----
             if kdefl % (2 * kexsh) == 0:
@@ -193,6 +313,9 @@ def hqr2_eigvals(hin, shifts="e44", stats=None, nb=2):
                         s1, p1, s2, p2 = bairstow_split(cp, a_ + d_, a_ * d_ - b_ * c_)
                         if all(math.isfinite(x) for x in (s1, p1, s2, p2)):
                             sA, pA, sB, pB = s1 * sc, p1 * sc * sc, s2 * sc, p2 * sc * sc
+            if aed_shifts and aed_pairs and kdefl % kexsh != 0:
+                sA, pA = aed_pairs[0]
+                sB, pB = aed_pairs[1] if len(aed_pairs) > 1 else aed_pairs[0]
             # ---- common start row: the largest m >= l at which BOTH start vectors may be launched ----
             m = i - 2
             while m > l:
@@ -279,6 +402,8 @@ def hqr2_eigvals(hin, shifts="e44", stats=None, nb=2):
                         sm = h[l:i + 1, k] + u1 * h[l:i + 1, k + 1]
                         h[l:i + 1, k] -= sm * t1
                         h[l:i + 1, k + 1] -= sm * t2
+        if converged is None:                     # the early-deflation window took the rest of the active block
+            continue
         if not converged:
             if stats is not None:
                 stats.update(sweeps=sweeps, steps=steps, iters=iters_total)

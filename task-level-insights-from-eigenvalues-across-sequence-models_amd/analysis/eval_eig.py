@@ -122,22 +122,20 @@ def _dev(a, dtype=None, device="cuda"):
 def discrete_DPLR(Lambda, P, Q, B, C, step, L, compute_bc=False):
     """Bilinear discretisation (eval_eig.py:254-278).  Returns (Ab, Bb, Cb).  ``Ab`` comes from the HIP kernel; the
     reference's callers discard ``Bb`` / ``Cb`` (quirk Q18), so they are only produced (torch ops on the device)
-    when ``compute_bc`` is set.  Only the Q == P form used by the reference (eval_eig.py:294) is supported."""
+    when ``compute_bc`` is set.  P and Q are separate as in the reference (its only caller passes Q = P, :294), and
+    Lambda is taken as given: the clip of Re(Lambda) is the caller's (:288), not this function's."""
     lam = _dev(Lambda, torch.complex128).reshape(1, -1)
     p = _dev(P, torch.complex128).reshape(1, -1)
     q = _dev(Q, torch.complex128).reshape(1, -1)
-    if not torch.equal(p, q):
-        raise NotImplementedError("discrete_DPLR: only Q == P (the reference's call, eval_eig.py:294) is in scope")
     step_t = torch.as_tensor(step, dtype=torch.float64, device=lam.device).reshape(1)
-    # the kernel clips Re(Lambda) at -1e-4 exactly like the caller at eval_eig.py:288 (idempotent for clipped input)
-    ab = ops.s4_dplr_build(lam.real, lam.imag, p, torch.log(step_t))[0]
+    ab = ops.s4_dplr_build(lam.real, lam.imag, p, torch.log(step_t), q=q, clip=False)[0]
     if not compute_bc:
         return ab, None, None
     n = lam.shape[1]
     g = 2.0 / step_t
     d = 1.0 / (g - lam[0])
-    denom = 1.0 + torch.sum(p[0].conj() * d * p[0])
-    a1 = torch.diag(d) - torch.outer(d * p[0], p[0].conj() * d) / denom
+    denom = 1.0 + torch.sum(q[0].conj() * d * p[0])
+    a1 = torch.diag(d) - torch.outer(d * p[0], q[0].conj() * d) / denom
     bb = 2 * a1 @ _dev(B, torch.complex128).reshape(-1, 1)
     eye = torch.eye(n, dtype=torch.complex128, device=lam.device)
     cb = _dev(C, torch.complex128).reshape(1, -1) @ torch.linalg.inv(eye - torch.linalg.matrix_power(ab, int(L))).conj()

@@ -31,8 +31,8 @@ int mamba2_lambda_launch(const float*, int64_t, int, int64_t, const float*, cons
 int mamba2_lti_launch(const float*, const float*, int, int64_t, float*, hipStream_t);
 int normattn_eta_launch(const float*, int64_t, int64_t, int, const float*, const float*, const float*, int, int,
                         double*, hipStream_t);
-int s4_dplr_launch(const double*, const double*, const double*, const double*, const double*, int64_t, int, double*,
-                   hipStream_t);
+int s4_dplr_launch(const double*, const double*, const double*, const double*, const double*, const double*,
+                   const double*, int64_t, int, int, double*, hipStream_t);
 size_t attn_workspace_bytes(int64_t, int64_t, int, int);
 int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, const float*, int, int, double*, void*,
                     size_t, hipStream_t);
@@ -123,7 +123,26 @@ int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const do
     EGS_ARG(p_im != nullptr, 4);
     EGS_ARG(log_step != nullptr, 5);
     EGS_ARG(ab != nullptr, 8);
-    return s4_dplr_launch(lambda_re, lambda_im, p_re, p_im, log_step, nmat, n, ab, as_stream(stream));
+    return s4_dplr_launch(lambda_re, lambda_im, p_re, p_im, p_re, p_im, log_step, nmat, n, 1, ab, as_stream(stream));
+}
+
+int egs_s4_dplr_build_pq(const double* lambda_re, const double* lambda_im, const double* p_re, const double* p_im,
+                         const double* q_re, const double* q_im, const double* log_step, int64_t nmat, int n,
+                         int clip_lambda, double* ab, egs_stream_t stream) {
+    EGS_ARG(nmat >= 0, 8);
+    EGS_ARG(n >= 0 && n <= 2048, 9);
+    if (nmat == 0 || n == 0) return 0;
+    EGS_ARG(lambda_re != nullptr, 1);
+    EGS_ARG(lambda_im != nullptr, 2);
+    EGS_ARG(p_re != nullptr, 3);
+    EGS_ARG(p_im != nullptr, 4);
+    EGS_ARG(q_re != nullptr, 5);
+    EGS_ARG(q_im != nullptr, 6);
+    EGS_ARG(log_step != nullptr, 7);
+    EGS_ARG(clip_lambda == 0 || clip_lambda == 1, 10);
+    EGS_ARG(ab != nullptr, 11);
+    return s4_dplr_launch(lambda_re, lambda_im, p_re, p_im, q_re, q_im, log_step, nmat, n, clip_lambda, ab,
+                          as_stream(stream));
 }
 
 static size_t eig_core_workspace_bytes(bool real, int64_t nmat, int n) {

@@ -394,8 +394,9 @@ __global__ void mamba2_lti_kernel(const float* __restrict__ a_param, const float
 }
 
 // ---------------------------------------------------------------------------------------------------
-// S4 DPLR build: Ab = A1 A0,  A0 = g I + diag(L) - P P^H,  A1 = D - (D P)(P^H D)/(1 + P^H D P), D = 1/(g - L)
-// Expanding the product row i, column j (c = P^H D P, r_i = D_i P_i, q_j = conj(P_j)):
+// S4 DPLR build: Ab = A1 A0,  A0 = g I + diag(L) - P Q^H,  A1 = D - (D P)(Q^H D)/(1 + Q^H D P), D = 1/(g - L)
+// (discrete_DPLR takes P and Q separately, analysis/eval_eig.py:254-273; its only caller passes Q = P, :294)
+// Expanding the product row i, column j (c = Q^H D P, r_i = D_i P_i, q_j = conj(Q_j)):
 //   Ab[i][j] = D_i (g + L_i) [i==j] - r_i q_j - r_i q_j D_j (g + L_j) / (1 + c) + r_i q_j s / (1 + c)
 // with s = sum_k conj(P_k) D_k P_k = c.  One workgroup per matrix; O(n^2) outputs, coalesced stores.
 // ---------------------------------------------------------------------------------------------------
@@ -415,24 +416,30 @@ __global__ __launch_bounds__(256) void s4_dplr_kernel(const double* __restrict__
                                                       const double* __restrict__ lam_im,
                                                       const double* __restrict__ p_re,
                                                       const double* __restrict__ p_im,
-                                                      const double* __restrict__ log_step, int n,
+                                                      const double* __restrict__ q_re,
+                                                      const double* __restrict__ q_im,
+                                                      const double* __restrict__ log_step, int n, int clip,
                                                       double* __restrict__ ab) {
     extern __shared__ double lds_d[];
     cplx* dl = reinterpret_cast<cplx*>(lds_d);        // D_i
     cplx* gl = dl + n;                                // g + L_i
     cplx* pp = gl + n;                                // P_i
+    cplx* qq = pp + n;                                // Q_i
     __shared__ double red[2 * 256];
     const int64_t m = blockIdx.x;
     const double g = 2.0 / exp(log_step[m]);
     double cre = 0.0, cim = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const cplx L = {fmin(lam_re[m * n + i], -1e-4), lam_im[m * n + i]};     // clip (Q11)
+        const double lre = lam_re[m * n + i];
+        const cplx L = {clip ? fmin(lre, -1e-4) : lre, lam_im[m * n + i]};      // clip (Q11): the caller's, eval_eig.py:288
         const cplx P = {p_re[m * n + i], p_im[m * n + i]};
+        const cplx Q = {q_re[m * n + i], q_im[m * n + i]};
         const cplx D = cinv({g - L.re, -L.im});
         dl[i] = D;
         gl[i] = {g + L.re, L.im};
         pp[i] = P;
-        const cplx t = cmul(cmul(cconj(P), D), P);
+        qq[i] = Q;
+        const cplx t = cmul(cmul(cconj(Q), D), P);
         cre += t.re;
         cim += t.im;
     }
@@ -449,14 +456,14 @@ __global__ __launch_bounds__(256) void s4_dplr_kernel(const double* __restrict__
     const cplx c = {red[0], red[256]};
     const cplx inv1c = cinv({1.0 + c.re, c.im});
     double* out = ab + m * 2 * (int64_t)n * n;
-    // A1[i][k] = D_i [i==k] - r_i conj(P_k) D_k inv1c ;  A0[k][j] = gl_k [k==j] - P_k conj(P_j)
-    // Ab[i][j] = A1[i][j] gl_j - (sum_k A1[i][k] P_k) conj(P_j)
+    // A1[i][k] = D_i [i==k] - r_i conj(Q_k) D_k inv1c ;  A0[k][j] = gl_k [k==j] - P_k conj(Q_j)
+    // Ab[i][j] = A1[i][j] gl_j - (sum_k A1[i][k] P_k) conj(Q_j)
     //   sum_k A1[i][k] P_k = D_i P_i - r_i inv1c c = r_i (1 - c inv1c) = r_i inv1c
     for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
         const int i = idx / n;
         const int j = idx - i * n;
         const cplx ri = cmul(dl[i], pp[i]);
-        const cplx qj = cconj(pp[j]);
+        const cplx qj = cconj(qq[j]);
         cplx a1ij = cmul(cmul(cmul(ri, qj), dl[j]), inv1c);
         a1ij = {-a1ij.re, -a1ij.im};
         if (i == j) a1ij = cadd(a1ij, dl[i]);
@@ -597,11 +604,12 @@ int mamba2_lti_launch(const float* a_param, const float* beta, int nheads, int64
 }
 
 int s4_dplr_launch(const double* lam_re, const double* lam_im, const double* p_re, const double* p_im,
-                   const double* log_step, int64_t nmat, int n, double* ab, hipStream_t stream) {
+                   const double* q_re, const double* q_im, const double* log_step, int64_t nmat, int n, int clip,
+                   double* ab, hipStream_t stream) {
     if (nmat == 0 || n == 0) return 0;
-    const size_t lds = (size_t)3 * n * 2 * sizeof(double);
+    const size_t lds = (size_t)4 * n * 2 * sizeof(double);
     hipLaunchKernelGGL(s4_dplr_kernel, dim3((unsigned)nmat), dim3(256), lds, stream, lam_re, lam_im, p_re, p_im,
-                       log_step, n, ab);
+                       q_re, q_im, log_step, n, clip, ab);
     EGS_LAUNCH_CHECK();
     return 0;
 }

@@ -28,6 +28,30 @@ def bootstrap():
     return world()
 
 
+def _env_flag(name):
+    """'1' / 'true' / 'yes' / 'on' (any case) switch a flag on; unset, empty, '0', 'false', 'no', 'off' leave it off."""
+    return os.environ.get(name, "").strip().lower() in ("1", "true", "yes", "on")
+
+
+_gather_sync_agreed = {}
+
+
+def gather_sync(group=None):
+    """EGS_GATHER_SYNC, read ONCE per process group and agreed over it: ranks that disagreed would mix the blocking
+    collective with the padded asynchronous one, and mismatched collectives deadlock.  The first call on a group is itself
+    a (tiny, host-side) collective: every rank of the group must reach it, which all_gather_slabs_async guarantees."""
+    key = id(group) if group is not None else 0
+    if key not in _gather_sync_agreed:
+        mine = _env_flag("EGS_GATHER_SYNC")
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            votes = [None] * dist.get_world_size(group)
+            dist.all_gather_object(votes, mine, group=group)
+            if len(set(votes)) != 1:
+                raise RuntimeError("EGS_GATHER_SYNC differs between ranks (%s): set it identically on every rank" % votes)
+        _gather_sync_agreed[key] = mine
+    return _gather_sync_agreed[key]
+
+
 def _host_staged(group=None):
     """gloo moves host memory: device slabs are staged through the host around the collective."""
     return dist.get_backend(group) == "gloo"
@@ -95,7 +119,7 @@ def all_gather_slabs_async(local, n_total, group=None):
     rank, world_size = world()
     if world_size == 1:
         return _GatherHandle(local, local.shape[0], local.device)
-    if (local.is_cuda and _host_staged(group)) or os.environ.get("EGS_GATHER_SYNC"):
+    if (local.is_cuda and _host_staged(group)) or gather_sync(group):
         # EGS_GATHER_SYNC=1: the blocking collective as a fallback (the overlapped form has only been rehearsed on a
         # one-rank RCCL group and on gloo: no multi-GPU node in reach of this build)
         return _GatherHandle(all_gather_slabs(local, n_total, group), n_total, local.device)

@@ -12,7 +12,8 @@ from . import _capi
 from ._capi import check, lib
 
 _workspaces = {}
-_workspace_caps = {}
+_workspace_caps = {}          # key -> {"asked": full request, "fitted": size that fitted, "calls": requests since then}
+_CAP_RETRY_CALLS = 16         # every that many requests the full size is tried again
 
 
 def _require_cuda(t, name):
@@ -40,9 +41,15 @@ def _workspace(device, nbytes, tag="scratch", floor=None):
     before the out-of-memory error is passed on, and the size that fitted is remembered for this key."""
     nbytes = max(int(nbytes), 256)
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    full = nbytes
     cap = _workspace_caps.get(key)
     if floor is not None and cap is not None:
-        nbytes = max(min(nbytes, cap), int(floor))
+        # a cap is the size that FITTED after an out-of-memory halving for a request of cap["asked"] bytes.  It holds for
+        # requests of that size for _CAP_RETRY_CALLS calls, then the full request is tried again: one transient shortage
+        # must not pin the stream to the slower several-pass form for the rest of the process (ADVICE r4)
+        cap["calls"] += 1
+        if cap["asked"] == full and cap["calls"] % _CAP_RETRY_CALLS != 0:
+            nbytes = max(min(nbytes, cap["fitted"]), int(floor))
     buf = _workspaces.get(key)
     if buf is not None and buf.numel() >= nbytes:
         return buf
@@ -52,13 +59,21 @@ def _workspace(device, nbytes, tag="scratch", floor=None):
     while True:
         try:
             _workspaces[key] = buf = torch.empty(want, dtype=torch.uint8, device=device)
+            if want < full:                         # recorded only once the smaller allocation has succeeded
+                if key not in _workspace_caps:
+                    import warnings
+                    warnings.warn("eigspec: %s workspace of %d bytes does not fit on %s, using %d (the n <= 64 solver runs "
+                                  "its batch in several passes: same spectra, lower throughput)" % (tag, full, device, want),
+                                  RuntimeWarning, stacklevel=3)
+                _workspace_caps[key] = {"asked": full, "fitted": want, "calls": 0}
+            else:
+                _workspace_caps.pop(key, None)
             return buf
         except torch.cuda.OutOfMemoryError:
             if floor is None or want <= int(floor):
                 raise
             torch.cuda.empty_cache()
             want = max(int(floor), want // 2)
-            _workspace_caps[key] = want
 
 
 def release_workspaces():
@@ -187,10 +202,12 @@ def diag_ssm_lambda(mode, p0, p1, p2=None):
     return out
 
 
-def s4_dplr_build(lambda_re, lambda_im, p, log_step):
-    """Ab [nmat, n, n] complex128 of the bilinear-discretised DPLR SSM (Q = P), for nmat feature columns.
+def s4_dplr_build(lambda_re, lambda_im, p, log_step, q=None, clip=True):
+    """Ab [nmat, n, n] complex128 of the bilinear-discretised DPLR SSM, for nmat feature columns.
 
-    lambda_re, lambda_im: [nmat, n] real; p: [nmat, n] complex (or real); log_step: [nmat]."""
+    lambda_re, lambda_im: [nmat, n] real; p: [nmat, n] complex (or real); log_step: [nmat].
+    q: None = the reference's call, Q = P (analysis/eval_eig.py:294), else [nmat, n] -- A = diag(Lambda) - P Q^H;
+    clip: Re(Lambda) <= -1e-4 as get_eigvals_ssm clips before the call (:288); False = Lambda as given."""
     _require_cuda(lambda_re, "lambda_re")
     lr = lambda_re.to(torch.float64).contiguous()
     li = lambda_im.to(torch.float64).contiguous()
@@ -201,8 +218,17 @@ def s4_dplr_build(lambda_re, lambda_im, p, log_step):
     nmat, n = lr.shape
     ab = torch.empty((nmat, n, n), dtype=torch.complex128, device=lr.device)
     with torch.cuda.device(lr.device):
-        check(lib().egs_s4_dplr_build(_ptr(lr), _ptr(li), _ptr(pr), _ptr(pi), _ptr(ls), nmat, n, _ptr(ab), _stream()),
-              "egs_s4_dplr_build")
+        if q is None and clip:
+            check(lib().egs_s4_dplr_build(_ptr(lr), _ptr(li), _ptr(pr), _ptr(pi), _ptr(ls), nmat, n, _ptr(ab), _stream()),
+                  "egs_s4_dplr_build")
+        else:
+            qc = pc if q is None else q.to(torch.complex128)
+            if tuple(qc.shape) != (nmat, n):
+                raise ValueError(f"q must be [nmat, n] = {(nmat, n)}, got {tuple(qc.shape)}")
+            qr = qc.real.contiguous()
+            qi = qc.imag.contiguous()
+            check(lib().egs_s4_dplr_build_pq(_ptr(lr), _ptr(li), _ptr(pr), _ptr(pi), _ptr(qr), _ptr(qi), _ptr(ls), nmat, n,
+                                             1 if clip else 0, _ptr(ab), _stream()), "egs_s4_dplr_build_pq")
     return ab
 
 

@@ -37,7 +37,8 @@ def test_bench_line_schema_and_consistency():
     # value = matrices per second of the timed steps
     assert abs(d["value"] - nmat / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["kernel"] == "eig_real64_kernel + hqr_tail_kernel" and r["bound"] in ("hbm", "mfma") and r["unit"] == "TFLOP/s"
+    # the n = 64 solver is fp64 vector arithmetic on an LDS-resident matrix (review r4 #3: it was mislabelled "mfma")
+    assert r["kernel"] == "eig_real64_kernel + hqr_tail_kernel" and r["bound"] == "valu+lds" and r["unit"] == "TFLOP/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # achieved = algorithmic flops per launch / measured launch time: (40/3) n^3 per matrix
     want = (40.0 / 3.0) * 64 ** 3 * nmat / (r["avg_launch_ms"] * 1e-3) / 1e12
@@ -46,6 +47,21 @@ def test_bench_line_schema_and_consistency():
     assert 0.5 * d["ms_per_step"] < r["avg_launch_ms"] <= 1.05 * d["ms_per_step"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # the pooled CPU figure says which share of the host it used, and labels the all-core number as an extrapolation
+    pool = d["cpu_baseline_pool"]
+    assert pool["cores"] >= 1 and pool["cores_of_host"] == "%d of %d" % (pool["cores"], pool["host_cpu_count"])
+    assert pool["sample"].startswith("%d of the host's %d cores" % (pool["cores"], pool["host_cpu_count"]))
+    assert "not a measurement" in pool["all_cores_extrapolated"]["how"]
+    # SURVEY 8(d)'s second C2 set rides along
+    gs = d["secondary_c2_gaussian"]
+    assert gs["unconverged"] == 0 and gs["max_abs_dlambda_vs_lapack"] < 1e-5 and gs["bound"] == "valu+lds"
+    assert abs(gs["frac"] - gs["achieved"] / gs["peak"]) < 1e-12 and gs["spectra_per_s"] > 0
+    # the level-3 path's stages carry their own bounds: the Hessenberg stage is memory-bound
+    c5 = [x for x in d["secondary_rooflines"] if x["workload"].startswith("C5")][0]
+    assert c5["stages"]["zhess_blocked_kernel"]["bound"] == "hbm" and "traffic" in c5["stages"]["zhess_blocked_kernel"]
+    # who ran: one rank, one device, a communicator of one
+    assert d["comm_size"] == 1 and d["distinct_devices"] == 1 and len(d["ranks"]) == 1 and d["ranks"][0]["rank"] == 0
+    assert d["ranks"][0]["uuid"] or d["ranks"][0]["pci_bus_id"] is not None or d["ranks"][0]["index"] == 0
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -64,6 +80,28 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["world"] == 2 and d["dist_backend"] == "gloo" and d["scaling"] == "weak"
     assert d["unconverged"] == 0 and d["max_abs_dlambda_vs_lapack"] < 1e-5
     assert abs(d["value"] - 2 * nmat / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # every rank reports the device it drove (here both on the one GPU: two ranks, ONE distinct device)
+    assert d["comm_size"] == 2 and [x["rank"] for x in d["ranks"]] == [0, 1] and d["distinct_devices"] == 1
+
+
+def test_bench_strong_scaling_splits_the_fixed_batch():
+    """`--scaling strong`: --nmat is the whole batch; two ranks (gloo-staged on the one GPU) take contiguous slabs of it --
+    5001 is not divisible by two, so the gather pads -- and config C4's batch is cut the same way."""
+    nmat = 5001
+    env = dict(os.environ, EGS_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--nmat", str(nmat), "--no-cpu", "--scaling", "strong"], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and d["config"]["matrices_total"] == nmat
+    assert d["config"]["matrices_per_gpu"] == 2501                      # rank 0's slab: ceil(5001 / 2)
+    assert abs(d["value"] - nmat / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["unconverged"] == 0 and d["max_abs_dlambda_vs_lapack"] < 1e-5
+    c4 = d["secondary_c4_strong"]
+    assert c4["scaling"] == "strong" and c4["sequences_per_rank"] == 2048 and c4["gathered_shape"] == [4096, 4095, 1]
 
 
 def test_pipelined_all_gather_on_a_one_rank_rccl_group(tmp_path):
@@ -125,6 +163,7 @@ h2 = pkg.dist.all_gather_slabs_async(full[lo:hi].clone(), n_total)
 a1, a2 = h1.wait(), h2.wait()
 s1 = pkg.dist.all_gather_slabs(cfull[lo:hi].clone(), n_total)
 os.environ["EGS_GATHER_SYNC"] = "1"
+pkg.dist._gather_sync_agreed.clear()                             # the flag is read once per group: re-read it (both ranks do)
 s2 = pkg.dist.all_gather_slabs_async(full[lo:hi].clone(), n_total).wait()
 torch.cuda.synchronize()
 ok = (torch.equal(torch.view_as_real(a1), torch.view_as_real(cfull)) and torch.equal(a2, full)
@@ -137,14 +176,23 @@ print("RCCL-TWO-RANKS", rank, "ok" if ok else "mismatch")
         env.pop(k, None)
     procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.PIPE, text=True) for r in range(2)]
-    outs = []
+    outs, timed_out = [], False
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=180))
+            outs.append(p.communicate(timeout=240))
         except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            pytest.skip("two RCCL ranks did not come up on this box")
+            timed_out = True
+            break
+    if timed_out:
+        # a hang of the multi-rank gather is a FAILURE, not a skip: stop both ranks, keep what they said
+        for q in procs:
+            q.kill()
+        outs = [q.communicate() for q in procs]
+        if any("Duplicate GPU" in e or "invalid usage" in e for _, e in outs):
+            pytest.skip("RCCL rejects two ranks on one device")
+        pytest.fail("two RCCL ranks did not finish within 240 s (deadlock in the multi-rank gather?):\n" +
+                    "\n".join("rank %d stdout: %s\nrank %d stderr: %s" % (r, o[-1500:], r, e[-3000:])
+                              for r, (o, e) in enumerate(outs)))
     if any("Duplicate GPU" in e or "invalid usage" in e for _, e in outs):
         pytest.skip("RCCL rejects two ranks on one device")
     for r, (p, (o, e)) in enumerate(zip(procs, outs)):

@@ -24,7 +24,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, tmp_path, tag, attention_fn, dropout, exchange=None):
+def _run(world, tmp_path, tag, attention_fn, dropout, exchange=None, backend="gloo"):
     sys.path.insert(0, HERE)
     import _dist_eval_worker as W
     torch.manual_seed(7)
@@ -37,12 +37,21 @@ def _run(world, tmp_path, tag, attention_fn, dropout, exchange=None):
         cwd = tmp_path / f"{tag}_rank{r}"
         os.mkdir(cwd)
         dirs.append(cwd)
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), EGS_DIST_BACKEND="gloo")
+        # gloo: both ranks on device 0, collectives staged through the host; nccl (= RCCL): one device per rank
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if backend == "gloo" else str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EGS_DIST_BACKEND=backend)
         spec = {"cwd": str(cwd), "ckpt": ckpt, "attention_fn": attention_fn, "dropout": dropout, "exchange": exchange}
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_eval_worker.py"), json.dumps(spec)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600)[0])
+    except subprocess.TimeoutExpired:
+        # a hang of the sharded path is a failure with evidence, never a skip: stop every rank and show what they printed
+        for q in procs:
+            q.kill()
+        pytest.fail("ranks did not finish within 600 s:\n" + "\n".join(q.communicate()[0][-3000:] for q in procs))
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     return dirs, [dict(np.load(d / "out.npz")) for d in dirs]
@@ -90,3 +99,24 @@ def test_histogram_only_exchange(tmp_path):
     cfg = yaml.safe_load(open(os.path.join(art[0], "used_config.yaml")))
     assert cfg["eigspec_sharding"] == {"exchange": "histogram", "world_size": 2, "rank": 0, "batch_rows": [0, nloc0],
                                        "batch_size": single["eig"].shape[0]}
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two RCCL ranks need two GPUs (RCCL rejects duplicate devices); "
+                                                          "the same comparison runs over gloo above")
+@pytest.mark.parametrize("exchange", [None, "histogram"])
+def test_two_rccl_ranks_equal_single_process(tmp_path, exchange):
+    """The same comparisons over RCCL (one device per rank) wherever the suite is given two GPUs: the gathered spectra,
+    and the histogram-only exchange (one all_reduce of the percentages, spectra stay on their GPU)."""
+    _, (single,) = _run(1, tmp_path, "w1", "lin-attention", 0.0)
+    _, ranks = _run(2, tmp_path, "w2r", "lin-attention", 0.0, exchange=exchange, backend="nccl")
+    lo = 0
+    for r in range(2):
+        for k in ("pct", "pct_init", "pct_phase", "pct_phase_init"):
+            np.testing.assert_array_equal(ranks[r][k], single[k])
+        if exchange == "histogram":
+            nloc = ranks[r]["eig"].shape[0]
+            np.testing.assert_allclose(ranks[r]["eig"], single["eig"][lo:lo + nloc], rtol=1e-12)
+            lo += nloc
+        else:
+            np.testing.assert_allclose(ranks[r]["eig"], single["eig"], rtol=1e-12)
+            np.testing.assert_allclose(ranks[r]["eig_init"], single["eig_init"], rtol=1e-12)

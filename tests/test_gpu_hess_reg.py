@@ -370,10 +370,20 @@ def test_workspace_falls_back_to_passes_under_memory_pressure(gpu_ops, monkeypat
         return real_empty(size, *args, **kw)
 
     monkeypatch.setattr(torch, "empty", stingy)
-    w, info = gpu_ops.eig_general_batched(a)
+    with pytest.warns(RuntimeWarning, match="several passes"):               # the throughput loss is made visible, once
+        w, info = gpu_ops.eig_general_batched(a)
     monkeypatch.undo()
     assert len(calls) >= 2 and int(info.abs().sum().item()) == 0
     assert torch.equal(torch.view_as_real(w), torch.view_as_real(w_ref))      # passes do not change a bit
+    # the cap was recorded only after the smaller allocation succeeded, for THIS request size ...
+    caps = list(gpu_ops._workspace_caps.values())
+    assert len(caps) == 1 and caps[0]["fitted"] <= need // 4 < caps[0]["asked"] == need
+    # ... and it is not for ever: with memory back, the full request is tried again within _CAP_RETRY_CALLS calls
+    for _ in range(gpu_ops._CAP_RETRY_CALLS):
+        w2, _ = gpu_ops.eig_general_batched(a)
+    assert not gpu_ops._workspace_caps
+    assert max(b.numel() for b in gpu_ops._workspaces.values()) >= need
+    assert torch.equal(torch.view_as_real(w2), torch.view_as_real(w_ref))
     gpu_ops.release_workspaces()
 
 

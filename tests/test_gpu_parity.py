@@ -127,6 +127,32 @@ def test_eig_real_large_batch_properties(gpu_ops):
     np.testing.assert_allclose(np.sort(np.abs(w), axis=1), np.sort(np.abs(lam), axis=1), atol=1e-9)
 
 
+def test_discrete_dplr_general_p_q_matches_reference_golden(pkg, gpu_ops, golden):
+    """The operator-level ``discrete_DPLR(Lambda, P, Q, B, C, step, L)`` with Q != P and Lambda as given (review r4 #5:
+    it used to raise NotImplementedError): Ab from the HIP kernel (egs_s4_dplr_build_pq, clip off), Bb / Cb on request."""
+    import importlib
+    ev = importlib.import_module(pkg.__name__ + ".analysis.eval_eig")
+    g = golden("dplr_pq")
+    for i in range(2):
+        args = (g[f"c{i}_Lambda"], g[f"c{i}_P"], g[f"c{i}_Q"], g[f"c{i}_B"], g[f"c{i}_C"], float(g[f"c{i}_step"]),
+                int(g[f"c{i}_L"]))
+        ab, bb, cb = ev.discrete_DPLR(*args)
+        assert bb is None and cb is None                                    # the reference's caller discards them (Q18)
+        np.testing.assert_allclose(ab.cpu().numpy(), g[f"c{i}_Ab"], rtol=1e-11, atol=1e-12)
+        ab, bb, cb = ev.discrete_DPLR(*args, compute_bc=True)
+        np.testing.assert_allclose(ab.cpu().numpy(), g[f"c{i}_Ab"], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(bb.cpu().numpy(), g[f"c{i}_Bb"], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(cb.cpu().numpy(), g[f"c{i}_Cb"], rtol=1e-8, atol=1e-9)
+    # Q = P through the general entry point, clip on, equals the original entry point bit for bit
+    rng = np.random.default_rng(7)
+    lam_re, lam_im = -np.abs(rng.standard_normal((3, 16))) + 0.05, rng.standard_normal((3, 16))
+    p = rng.standard_normal((3, 16)) + 1j * rng.standard_normal((3, 16))
+    ls = np.log(rng.uniform(1e-3, 1e-1, 3))
+    a1 = gpu_ops.s4_dplr_build(dev(lam_re), dev(lam_im), dev(p), dev(ls))
+    a2 = gpu_ops.s4_dplr_build(dev(lam_re), dev(lam_im), dev(p), dev(ls), q=dev(p), clip=True)
+    assert torch.equal(torch.view_as_real(a1), torch.view_as_real(a2))
+
+
 # ---- K5 complex ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 2, 3, 8, 33, 64, 96, 97, 130])
 def test_eig_complex_matches_lapack(gpu_ops, n):

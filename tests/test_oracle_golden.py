@@ -98,6 +98,19 @@ def test_s4_dplr_and_eigs_match_reference(golden):
         assert O.max_abs_dlambda(w[:, 0], g[f"s4_{i}_eig"][:, 0]) < 1e-11
 
 
+def test_discrete_dplr_with_separate_p_and_q_matches_reference(golden):
+    """discrete_DPLR's general form (analysis/eval_eig.py:254-278): A = diag(Lambda) - P Q^H with Q != P and an unclipped
+    Lambda (the clip is the caller's, :288) -- golden from the reference's own function (make_golden_dplr_pq.py)."""
+    g = golden("dplr_pq")
+    for i in range(2):
+        Ab, Bb, Cb = O.discrete_dplr(g[f"c{i}_Lambda"], g[f"c{i}_P"], g[f"c{i}_Q"], g[f"c{i}_B"], g[f"c{i}_C"],
+                                     float(g[f"c{i}_step"]), int(g[f"c{i}_L"]))
+        assert np.max(g[f"c{i}_Lambda"].real) > -1e-4                      # the case really exercises "no clip here"
+        np.testing.assert_allclose(Ab, g[f"c{i}_Ab"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(Bb, g[f"c{i}_Bb"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(Cb, g[f"c{i}_Cb"], rtol=1e-9, atol=1e-10)
+
+
 def test_s4_cayley_known_answer():
     """LAPACK-independent structure check: Ab = (g - A)^{-1} (g + A) with g = 2/step, so
     eig(Ab) = (g + a)/(g - a) for a in eig(A)."""
