@@ -599,6 +599,18 @@ def stream_rooflines(ops, device):
     tf_q = 4.0 * 10.0 * n ** 3 * h / (qr_ms * 1e-3) / 1e12
     tr = torch.diagonal(ab, dim1=1, dim2=2).sum(dim=1)
     trerr = float(((ww.sum(dim=1) - tr).abs() / torch.linalg.matrix_norm(ab)).max().item())
+    # the optional structured path (`s4_solver: dplr`): same 768 columns from the secular equation of diag(Lambda) - P P^H,
+    # no matrix formed.  At initialisation every column shares (Lambda, P): ONE solve; "all_columns" disables that sharing
+    # (what 768 differently TRAINED columns would cost).  The line's C5 figure stays the dense solver's.
+    pr = (dd(np.tile(lam.real, (h, 1))), dd(np.tile(lam.imag, (h, 1))), dd(np.tile(p, (h, 1))), dd(ls))
+    ms_shared = med(lambda: ops.s4_dplr_eigs(*pr), reps=3)
+    ms_all = med(lambda: ops.s4_dplr_eigs(*pr, dedupe=False), reps=3)
+    wf, inf_f = ops.s4_dplr_eigs(*pr, dedupe=False)
+    dplr = {"kernel": "dplr_secular_kernel + s4_cayley_map_kernel", "ms_shared_solve": ms_shared, "ms_all_columns": ms_all,
+            "unconverged": int((inf_f != 0).sum().item()),
+            "note": "eig(Ab) = (g + a)/(g - a), a = roots of 1 - sum |P_k|^2/(Lambda_k - a) (Ehrlich-Aberth, O(n^2) per "
+                    "iteration); agrees with the dense path by backward error on these raw-HiPPO columns "
+                    "(tests/test_gpu_dplr_secular.py); optional analysis key s4_solver: dplr"}
     # counted HBM-side traffic of the Hessenberg stage (PMC, profiles/rNN_traffic.json; null when stale): its level-2 half
     # re-reads the trailing matrix once per column, so the stage is MEMORY-bound -- priced against the HBM peak
     hz_traffic, hz_src, hz_note = kernel_traffic_launch("zhess_blocked_kernel<16, 2>", "zhess_blocked_kernel")
@@ -607,7 +619,7 @@ def stream_rooflines(ops, device):
                 "bound": "hbm (Hessenberg stage) + lds/valu behind barriers, mfma in the deferred updates (QR stage)",
                 "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
                 "ms": hs_ms + qr_ms, "spectra_per_s": h / ((hs_ms + qr_ms) * 1e-3), "unconverged": unconv,
-                "max_rel_trace_error": trerr,
+                "max_rel_trace_error": trerr, "structured_fast_path": dplr,
                 "stages": {"zhess_blocked_kernel": {"bound": "hbm", "ms": hs_ms, "achieved_tflops": tf_h,
                                                     "frac_of_fp64_peak": tf_h / FP64_PEAK_TFLOPS,
                                                     "traffic": hz_traffic, "traffic_source": hz_src, "traffic_note": hz_note,

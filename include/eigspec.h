@@ -83,6 +83,23 @@ int egs_s4_dplr_build_pq(const double* lambda_re, const double* lambda_im, const
                          const double* log_step, int64_t nmat, int n, int clip_lambda,
                          double* ab, egs_stream_t stream);
 
+/* ---- S4 fast path: eigenvalues from the DPLR structure (optional; the dense solver stays the default) ----------
+ * eig(Ab) without forming Ab: Ab = (gI - A)^-1 (gI + A) with A = diag(Lambda) - P Q^H and g = 2/step
+ * (analysis/eval_eig.py:260-273), so eig(Ab) = (g + a)/(g - a), a in eig(A) -- and A, diagonal plus rank one, has its
+ * eigenvalues at the roots of 1 - sum_k conj(Q_k) P_k / (Lambda_k - a) (Ehrlich-Aberth iteration, O(n^2) per sweep).
+ * Replaces the pair discrete_DPLR + np.linalg.eigvals (analysis/eval_eig.py:294-296) when the analysis YAML sets
+ * `s4_solver: dplr`.  Root by root backward stable (each value is an exact eigenvalue of A with P perturbed by O(n ulp)
+ * elementwise); on ill-conditioned spectra (raw HiPPO, N >= 64) it agrees with the dense path by backward error only.
+ *   egs_dplr_rank1_eigvals: lambda_*, p_*, q_* : double[nmat, n];  a : complex128[nmat, n] = eig(diag(Lambda) - P Q^H);
+ *       info[m] = number of roots of set m that did not converge (0 = ok).  clip_lambda as in egs_s4_dplr_build_pq.
+ *   egs_s4_cayley_map: w[c, :] = (g_c + a[s, :]) / (g_c - a[s, :]), g_c = 2/exp(log_step[c]), s = set_index[c] (or c when
+ *       set_index is null): `a` does not depend on the step, so columns sharing (Lambda, P, Q) share ONE solve. */
+int egs_dplr_rank1_eigvals(const double* lambda_re, const double* lambda_im, const double* p_re,
+                           const double* p_im, const double* q_re, const double* q_im, int64_t nmat, int n,
+                           int clip_lambda, double* a, int32_t* info, egs_stream_t stream);
+int egs_s4_cayley_map(const double* a, const int32_t* set_index, const double* log_step, int64_t ncol, int n,
+                      double* w, egs_stream_t stream);
+
 /* ---- K5: batched dense non-symmetric eigenvalues -------------------------------------------------
  * Replaces np.linalg.eigvals (LAPACK ?geev, analysis/eval_eig.py:296), generalised from one matrix per
  * layer to a batch.  Householder reduction to Hessenberg form + shifted QR (Francis double-shift for real

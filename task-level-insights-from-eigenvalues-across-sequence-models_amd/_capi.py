@@ -34,6 +34,8 @@ SIGNATURES = {
     "egs_diag_ssm_lambda": (_i, [_i, _vp, _vp, _vp, _i64, _vp, _vp]),
     "egs_s4_dplr_build": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "egs_s4_dplr_build_pq": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "egs_dplr_rank1_eigvals": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "egs_s4_cayley_map": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "egs_eig_workspace_bytes": (_sz, [_i, _i64, _i]),
     "egs_eig_general_batched": (_i, [_vp, _i, _i64, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     "egs_hessenberg_general_batched": (_i, [_vp, _i, _i64, _i, _i, _i64, _vp, _vp, _vp, _vp]),

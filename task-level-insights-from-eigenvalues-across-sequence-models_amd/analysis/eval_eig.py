@@ -8,7 +8,7 @@ Differences that are deliberate and documented in DESIGN.md:
   * when ``torch.distributed`` is initialised the analysis batch is sharded across ranks and the spectra are
     collected with one all-gather (``..dist``); the reference is single-process;
   * optional analysis-YAML keys (all default to the reference's behaviour): ``ssm_dtype`` ("complex128" |
-    "complex64"), ``s4_all_columns`` (bool), ``ssm_init`` ("jax" | "numpy").
+    "complex64"), ``s4_all_columns`` (bool), ``ssm_init`` ("jax" | "numpy"), ``s4_solver`` ("dense" | "dplr").
 """
 import os
 import tempfile
@@ -146,7 +146,23 @@ def _ssm_cast(w, dtype):
     return w.astype(np.complex64) if dtype == "complex64" else w
 
 
-def get_eigvals_ssm(model, layer_list, layer_nr, idx, SEQ_LEN, dtype="complex128"):
+def _s4_spectra(lam_re, lam_im, p, log_step, solver):
+    """eig(Ab) of `ncol` feature columns (eval_eig.py:285-296).  solver "dense" (default; the reference's arithmetic):
+    DPLR build + batched Hessenberg / QR; "dplr" (analysis key ``s4_solver: dplr``): the eigenvalues of
+    diag(Lambda) - P P^H from the secular equation, Cayley-mapped per column -- no matrix is formed, columns sharing
+    (Lambda, P) share one solve."""
+    if solver == "dplr":
+        w, info = ops.s4_dplr_eigs(lam_re, lam_im, p, log_step)
+    elif solver == "dense":
+        ab = ops.s4_dplr_build(lam_re, lam_im, p, log_step)             # eval_eig.py:285-294
+        w, info = ops.eig_general_batched(ab)                          # eval_eig.py:296
+    else:
+        raise ValueError("analysis config key 's4_solver' must be 'dense' or 'dplr', got {0!r}".format(solver))
+    _raise_on_info(info)
+    return w
+
+
+def get_eigvals_ssm(model, layer_list, layer_nr, idx, SEQ_LEN, dtype="complex128", s4_solver="dense"):
     """(N, 1) complex ndarray (eval_eig.py:281-333); prints and returns None for an unknown family (:331-333).
     ``layer_list[layer_nr]`` maps parameter names to arrays with the flax layouts (models/s4.py:183-189,
     models/s5.py:154-155, :218-222, models/lru.py:55-61)."""
@@ -156,9 +172,7 @@ def get_eigvals_ssm(model, layer_list, layer_nr, idx, SEQ_LEN, dtype="complex128
         lam_re = _dev(np.asarray(layer["Lambda_re"])[:, idx].reshape(1, -1), torch.float64)
         lam_im = _dev(np.asarray(layer["Lambda_im"])[:, idx].reshape(1, -1), torch.float64)
         p = _dev(np.asarray(layer["P"])[:, idx].reshape(1, -1), torch.complex128)
-        ab = ops.s4_dplr_build(lam_re, lam_im, p, log_step)             # eval_eig.py:285-294
-        w, info = ops.eig_general_batched(ab)                          # eval_eig.py:296
-        _raise_on_info(info)
+        w = _s4_spectra(lam_re, lam_im, p, log_step, s4_solver)
         return _ssm_cast(w.cpu().numpy().reshape(-1, 1), dtype)
     if model in ["s5"]:
         layer = layer_list[layer_nr]
@@ -174,7 +188,7 @@ def get_eigvals_ssm(model, layer_list, layer_nr, idx, SEQ_LEN, dtype="complex128
         return None
 
 
-def get_eigvals_s4_all(layer_list, dtype="complex128"):
+def get_eigvals_s4_all(layer_list, dtype="complex128", s4_solver="dense"):
     """Generalisation of the S4 branch from the single column ``idx = 1`` (quirk Q9) to every (layer, feature) column:
     one batched DPLR build + one batched eigensolve.  Returns (N, H, num_layers) complex."""
     lam_re, lam_im, p, ls = [], [], [], []
@@ -184,10 +198,8 @@ def get_eigvals_s4_all(layer_list, dtype="complex128"):
         p.append(np.asarray(layer["P"]).T)
         ls.append(np.asarray(layer["log_step"])[0])
     nl, h, n = len(layer_list), lam_re[0].shape[0], lam_re[0].shape[1]
-    ab = ops.s4_dplr_build(_dev(np.concatenate(lam_re), torch.float64), _dev(np.concatenate(lam_im), torch.float64),
-                           _dev(np.concatenate(p), torch.complex128), _dev(np.concatenate(ls), torch.float64))
-    w, info = ops.eig_general_batched(ab)
-    _raise_on_info(info)
+    w = _s4_spectra(_dev(np.concatenate(lam_re), torch.float64), _dev(np.concatenate(lam_im), torch.float64),
+                    _dev(np.concatenate(p), torch.complex128), _dev(np.concatenate(ls), torch.float64), s4_solver)
     return _ssm_cast(w.cpu().numpy().reshape(nl, h, n).transpose(2, 1, 0), dtype)
 
 
@@ -545,13 +557,16 @@ def eval_eig(args, conf_args, wandb_config, data_config, loader, path_file, perf
             init_layers = get_init_layers_ssm(seed, data_config, train_config, model_config, SEQ_LEN,
                                               model_classes[layer_type], batch_size)
         trained_layers = get_trained_layers_ssm(path)
+        s4_solver = conf_args.get("s4_solver", "dense")
+        if s4_solver not in ("dense", "dplr"):
+            raise ValueError("analysis config key 's4_solver' must be 'dense' or 'dplr', got {0!r}".format(s4_solver))
         if layer_type == "s4" and conf_args.get("s4_all_columns", False):
-            eig_init = get_eigvals_s4_all(init_layers, ssm_dtype).reshape(-1, num_layers)
-            eig = get_eigvals_s4_all(trained_layers, ssm_dtype).reshape(-1, num_layers)
+            eig_init = get_eigvals_s4_all(init_layers, ssm_dtype, s4_solver).reshape(-1, num_layers)
+            eig = get_eigvals_s4_all(trained_layers, ssm_dtype, s4_solver).reshape(-1, num_layers)
         else:
-            eig_init = np.concatenate([get_eigvals_ssm(layer_type, init_layers, i, dim_idx, SEQ_LEN, ssm_dtype)
+            eig_init = np.concatenate([get_eigvals_ssm(layer_type, init_layers, i, dim_idx, SEQ_LEN, ssm_dtype, s4_solver)
                                        for i in range(num_layers)], axis=-1)
-            eig = np.concatenate([get_eigvals_ssm(layer_type, trained_layers, i, dim_idx, SEQ_LEN, ssm_dtype)
+            eig = np.concatenate([get_eigvals_ssm(layer_type, trained_layers, i, dim_idx, SEQ_LEN, ssm_dtype, s4_solver)
                                   for i in range(num_layers)], axis=-1)
         thresholds_radius = np.array(THRESHOLDS_RADIUS)
         thresholds_phase = np.array(THRESHOLDS_PHASE)

@@ -33,6 +33,9 @@ int normattn_eta_launch(const float*, int64_t, int64_t, int, const float*, const
                         double*, hipStream_t);
 int s4_dplr_launch(const double*, const double*, const double*, const double*, const double*, const double*,
                    const double*, int64_t, int, int, double*, hipStream_t);
+int dplr_secular_launch(const double*, const double*, const double*, const double*, const double*, const double*, int64_t,
+                        int, int, double*, int32_t*, hipStream_t);
+int s4_cayley_map_launch(const double*, const int32_t*, const double*, int64_t, int, double*, hipStream_t);
 size_t attn_workspace_bytes(int64_t, int64_t, int, int);
 int attn_eta_launch(bool, const float*, int64_t, int64_t, int, const float*, const float*, int, int, double*, void*,
                     size_t, hipStream_t);
@@ -124,6 +127,36 @@ int egs_s4_dplr_build(const double* lambda_re, const double* lambda_im, const do
     EGS_ARG(log_step != nullptr, 5);
     EGS_ARG(ab != nullptr, 8);
     return s4_dplr_launch(lambda_re, lambda_im, p_re, p_im, p_re, p_im, log_step, nmat, n, 1, ab, as_stream(stream));
+}
+
+int egs_dplr_rank1_eigvals(const double* lambda_re, const double* lambda_im, const double* p_re, const double* p_im,
+                           const double* q_re, const double* q_im, int64_t nmat, int n, int clip_lambda, double* a,
+                           int32_t* info, egs_stream_t stream) {
+    EGS_ARG(nmat >= 0, 7);
+    EGS_ARG(n >= 0 && n <= 2048, 8);
+    if (nmat == 0 || n == 0) return 0;
+    EGS_ARG(lambda_re != nullptr, 1);
+    EGS_ARG(lambda_im != nullptr, 2);
+    EGS_ARG(p_re != nullptr, 3);
+    EGS_ARG(p_im != nullptr, 4);
+    EGS_ARG(q_re != nullptr, 5);
+    EGS_ARG(q_im != nullptr, 6);
+    EGS_ARG(clip_lambda == 0 || clip_lambda == 1, 9);
+    EGS_ARG(a != nullptr, 10);
+    EGS_ARG(info != nullptr, 11);
+    return dplr_secular_launch(lambda_re, lambda_im, p_re, p_im, q_re, q_im, nmat, n, clip_lambda, a, info,
+                               as_stream(stream));
+}
+
+int egs_s4_cayley_map(const double* a, const int32_t* set_index, const double* log_step, int64_t ncol, int n, double* w,
+                      egs_stream_t stream) {
+    EGS_ARG(ncol >= 0, 4);
+    EGS_ARG(n >= 0, 5);
+    if (ncol == 0 || n == 0) return 0;
+    EGS_ARG(a != nullptr, 1);
+    EGS_ARG(log_step != nullptr, 3);
+    EGS_ARG(w != nullptr, 6);
+    return s4_cayley_map_launch(a, set_index, log_step, ncol, n, w, as_stream(stream));
 }
 
 int egs_s4_dplr_build_pq(const double* lambda_re, const double* lambda_im, const double* p_re, const double* p_im,

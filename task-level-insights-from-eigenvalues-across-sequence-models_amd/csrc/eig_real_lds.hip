@@ -1869,7 +1869,10 @@ __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
     extern __shared__ __attribute__((aligned(16))) double smem_fused[];
     constexpr int n = 64, ldp = kLd64;
     const int lane0 = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
+    // wave-uniform BY CONSTRUCTION, which the compiler cannot see through threadIdx: as a scalar, everything derived from
+    // it (this wave's LDS halves, its scratch slot, its first matrix) lives in SGPRs instead of being spilled as
+    // per-lane values across the register-hungry reduction
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     double* base = smem_fused + (size_t)(wave >> 1) * kFusedPairDoubles;
     double* vecs = smem_fused + 2 * kFusedPairDoubles + (size_t)wave * kRegVec;
     const int64_t first = (int64_t)blockIdx.x * kFusedWaves + wave;

@@ -232,6 +232,50 @@ def s4_dplr_build(lambda_re, lambda_im, p, log_step, q=None, clip=True):
     return ab
 
 
+def s4_dplr_eigs(lambda_re, lambda_im, p, log_step, q=None, clip=True, dedupe=True):
+    """Eigenvalues of the bilinear-discretised DPLR state matrix WITHOUT forming it (analysis key `s4_solver: dplr`):
+    eig(Ab) = (g + a)/(g - a), a in eig(diag(Lambda) - P Q^H) from the secular equation (egs_dplr_rank1_eigvals), g = 2/step.
+
+    lambda_re, lambda_im: [ncol, n]; p (q): [ncol, n] complex; log_step: [ncol].  Returns (w complex128 [ncol, n],
+    info int32 [ncol]).  dedupe: columns whose (Lambda, P, Q) agree bit for bit share one solve (`a` does not depend on the
+    step) -- every column of a HiPPO-initialised layer does.  Replaces discrete_DPLR + np.linalg.eigvals
+    (analysis/eval_eig.py:294-296); agrees with the dense path to rounding on well-conditioned spectra and by backward
+    error on ill-conditioned ones."""
+    _require_cuda(lambda_re, "lambda_re")
+    lr = lambda_re.to(torch.float64).contiguous()
+    li = lambda_im.to(torch.float64).contiguous()
+    pc = p.to(torch.complex128)
+    qc = pc if q is None else q.to(torch.complex128)
+    ls = log_step.to(torch.float64).contiguous().reshape(-1)
+    ncol, n = lr.shape
+    if tuple(pc.shape) != (ncol, n) or tuple(qc.shape) != (ncol, n) or ls.numel() != ncol:
+        raise ValueError(f"expected [ncol, n] = {(ncol, n)} parameters and [ncol] log_step")
+    w = torch.empty((ncol, n), dtype=torch.complex128, device=lr.device)
+    if ncol == 0 or n == 0:
+        return w, torch.zeros((ncol,), dtype=torch.int32, device=lr.device)
+    planes = [lr, li, pc.real.contiguous(), pc.imag.contiguous(), qc.real.contiguous(), qc.imag.contiguous()]
+    set_index = None
+    if dedupe and ncol > 1:
+        # index plumbing, not arithmetic: group the columns by the BITS of their parameters
+        key = torch.cat([t.view(torch.int64) for t in planes], dim=1)
+        _, inverse = torch.unique(key, dim=0, return_inverse=True)
+        nuniq = int(inverse.max().item()) + 1
+        if nuniq < ncol:
+            first = torch.full((nuniq,), ncol, dtype=torch.int64, device=lr.device)
+            first.scatter_reduce_(0, inverse, torch.arange(ncol, device=lr.device), reduce="amin")
+            planes = [t[first].contiguous() for t in planes]
+            set_index = inverse.to(torch.int32).contiguous()
+    nset = planes[0].shape[0]
+    a = torch.empty((nset, n), dtype=torch.complex128, device=lr.device)
+    info_set = torch.empty((nset,), dtype=torch.int32, device=lr.device)
+    with torch.cuda.device(lr.device):
+        check(lib().egs_dplr_rank1_eigvals(*[_ptr(t) for t in planes], nset, n, 1 if clip else 0, _ptr(a), _ptr(info_set),
+                                           _stream()), "egs_dplr_rank1_eigvals")
+        check(lib().egs_s4_cayley_map(_ptr(a), _ptr(set_index), _ptr(ls), ncol, n, _ptr(w), _stream()), "egs_s4_cayley_map")
+    info = info_set if set_index is None else info_set[set_index.long()]
+    return w, info
+
+
 # ---- K2 -------------------------------------------------------------------------------------------------
 def mamba2_lambda(x, w_dt, b_dt, dt_bias, a_log):
     """x [B, L, D] fp32 -> lambda [B, L, nheads] fp32 (analysis/eval_eig.py:176-190)."""
