@@ -185,7 +185,14 @@ int egs_mamba2_lti_lambda(const float* a_param, const float* beta, int nheads, i
  *   workspace: egs_attn_workspace_bytes(B, L, d_qk, H) bytes (projected q,k in fp32, nu / row max scratch).
  * linear : nu_t = phi(q_t) . sum_{s<=t} phi(k_s), phi = elu + 1; nu == 0 -> 2e-23 (Q6); eta_t = nu_t / nu_{t+1}.
  * softmax: scores q_t.k_s (no 1/sqrt(d), Q3); m_t = max(max_{s<=t} score, 0 if t < L-1) (Q5);
- *          nu_t = sum_{s<=t} exp(score - m_t) + (L-1-t) (Q4); eta_t = nu_t/nu_{t+1} * exp(m_t - m_{t+1}). */
+ *          nu_t = sum_{s<=t} exp(score - m_t) + (L-1-t) (Q4); eta_t = nu_t/nu_{t+1} * exp(m_t - m_{t+1}).
+ *          Accuracy: WITHIN THE REFERENCE'S OWN fp32 ERROR, NOT BIT-FAITHFUL to its rounding.  One pass with a running row
+ *          maximum: the maximum is subtracted in fp32 as at analysis/eval_eig.py:62-72, exp runs in fp32 with an exact
+ *          range reduction (1.5e-7 relative; the reference's np.exp is fp64 on fp32 differences), the row sums are fp64
+ *          and are rescaled exactly when the maximum rises.  Against the fp64-exact value of the same formula the result
+ *          stays within 2 x the reference's own deviation (tests/test_gpu_parity.py).  Scores that are NaN or +-inf are
+ *          OUTSIDE the contract: the running maximum ignores NaN where torch.max propagates it (the reference's row
+ *          becomes 0 / NaN), and an infinite score gives inf - inf.  Finite inputs of any magnitude are covered. */
 size_t egs_attn_workspace_bytes(int64_t batch, int64_t seqlen, int d_qk, int num_heads);
 int egs_linattn_eta(const float* x, int64_t batch, int64_t seqlen, int d_model, const float* w_qk,
                     const float* b_qk, int d_qk, int num_heads, double* eta, void* workspace,

@@ -12,7 +12,12 @@ module decodes exactly that file with the ``msgpack`` package, which is what ``g
 Parity unpinned: orbax / flax are not installed in this image and the reference ships no checkpoint, so the decoder is
 written against the published serialisation format and is exercised with fixtures written by ``write_aggregate``
 below (same format, round trip) -- not with a file produced by orbax itself.  Parameters that orbax stored outside the
-aggregate file (tensorstore / OCDBT, used for multi-device arrays) show up as ``PLACEHOLDER://`` strings and raise.
+aggregate file show up as ``PLACEHOLDER://<flattened.key.path>`` strings.  When the directory holds such a leaf as a
+plain **zarr v2** array (``<dir>/<flattened.key.path>/.zarray`` + chunk files: what tensorstore's zarr driver writes
+without OCDBT) it is decoded here from the published zarr v2 layout -- uncompressed chunks and the compressors Python's
+standard library has (zlib / gzip, bz2, lzma); zstd / blosc chunks (orbax's usual choice) and OCDBT containers
+(``manifest.ocdbt``) raise with the reason.  This reader is **parity unpinned** like the rest of the module: its test
+builds the directory from the zarr v2 specification, nothing in this image can write one with tensorstore.
 """
 import os
 
@@ -65,13 +70,84 @@ def _unchunk(tree):
     return tree
 
 
-def _check_placeholders(tree, prefix=""):
+def _zarr_decompress(buf, compressor, where):
+    if compressor is None:
+        return buf
+    cid = compressor.get("id")
+    if cid in ("zlib", "gzip"):
+        import zlib
+        return zlib.decompress(buf, 15 + 32)                 # zlib or gzip header, detected
+    if cid == "bz2":
+        import bz2
+        return bz2.decompress(buf)
+    if cid == "lzma":
+        import lzma
+        return lzma.decompress(buf)
+    raise NotImplementedError(f"{where}: chunks are compressed with {cid!r}; only uncompressed, zlib / gzip, bz2 and lzma "
+                              "zarr chunks can be decoded here (no zstd / blosc codec in this environment)")
+
+
+def read_zarr_v2(path):
+    """One zarr v2 array directory (``.zarray`` + chunk files ``i.j.k`` / ``i/j/k``) as a NumPy array -- the layout
+    tensorstore's zarr driver gives an orbax parameter stored outside the aggregate file
+    (jax_helpers/train_helpers.py:395-409 saves through ``ocp.PyTreeCheckpointer``).  Written from the zarr v2
+    specification: C or F order inside a chunk, edge chunks stored at full chunk size, missing chunks = ``fill_value``."""
+    import itertools
+    import json
+    meta_file = os.path.join(path, ".zarray")
+    with open(meta_file) as f:
+        meta = json.load(f)
+    if meta.get("zarr_format") != 2:
+        raise NotImplementedError(f"{meta_file}: zarr_format {meta.get('zarr_format')!r}, only version 2 is decoded")
+    if meta.get("filters"):
+        raise NotImplementedError(f"{meta_file}: filters {meta['filters']!r} are not decoded")
+    shape, chunks = tuple(int(v) for v in meta["shape"]), tuple(int(v) for v in meta["chunks"])
+    dtype = np.dtype(meta["dtype"]) if isinstance(meta["dtype"], str) else np.dtype([tuple(t) for t in meta["dtype"]])
+    order = meta.get("order", "C")
+    sep = meta.get("dimension_separator", ".")
+    fill = meta.get("fill_value")
+    if fill in ("NaN", "Infinity", "-Infinity"):
+        fill = {"NaN": np.nan, "Infinity": np.inf, "-Infinity": -np.inf}[fill]
+    out = np.zeros(shape, dtype=dtype) if fill is None else np.full(shape, fill, dtype=dtype)
+    if len(shape) == 0:
+        fname = os.path.join(path, "0")
+        if os.path.isfile(fname):
+            with open(fname, "rb") as f:
+                out[...] = np.frombuffer(_zarr_decompress(f.read(), meta.get("compressor"), fname), dtype=dtype)[0]
+        return out
+    grid = [range((n + c - 1) // c) for n, c in zip(shape, chunks)]
+    for idx in itertools.product(*grid):
+        fname = os.path.join(path, sep.join(str(i) for i in idx)) if sep == "." else os.path.join(path, *[str(i) for i in idx])
+        if not os.path.isfile(fname):
+            continue                                          # an unwritten chunk reads as fill_value
+        with open(fname, "rb") as f:
+            raw = _zarr_decompress(f.read(), meta.get("compressor"), fname)
+        block = np.frombuffer(raw, dtype=dtype)
+        if block.size != int(np.prod(chunks)):
+            raise ValueError(f"{fname}: {block.size} elements, the chunk shape {chunks} needs {int(np.prod(chunks))}")
+        block = block.reshape(chunks, order=order)
+        sel = tuple(slice(i * c, min((i + 1) * c, n)) for i, c, n in zip(idx, chunks, shape))
+        out[sel] = block[tuple(slice(0, s.stop - s.start) for s in sel)]
+    return out.astype(dtype.newbyteorder("="), copy=False)
+
+
+def _resolve_placeholders(tree, root, prefix=""):
+    """Replace PLACEHOLDER:// leaves by the arrays tensorstore stored beside the aggregate file (zarr v2 only)."""
     if isinstance(tree, dict):
-        for k, v in tree.items():
-            _check_placeholders(v, f"{prefix}/{k}")
-    elif isinstance(tree, str) and tree.startswith("PLACEHOLDER://"):
-        raise NotImplementedError(f"{prefix} was stored outside the aggregate file ({tree}): tensorstore / OCDBT "
-                                  "parameter files are not decoded here")
+        return {k: _resolve_placeholders(v, root, f"{prefix}/{k}") for k, v in tree.items()}
+    if isinstance(tree, str) and tree.startswith("PLACEHOLDER://"):
+        name = tree[len("PLACEHOLDER://"):]
+        leaf = os.path.join(root, name) if root else None
+        if leaf and os.path.isfile(os.path.join(leaf, ".zarray")):
+            return read_zarr_v2(leaf)
+        why = "tensorstore / OCDBT parameter files are not decoded here"
+        if root and (os.path.exists(os.path.join(root, "manifest.ocdbt")) or
+                     any(n.startswith("ocdbt.process_") for n in os.listdir(root))):
+            why = "the directory is an OCDBT container (manifest.ocdbt), which is not decoded here"
+        elif leaf and os.path.isdir(leaf):
+            why = f"{leaf} holds no .zarray (not a zarr v2 array)"
+        raise NotImplementedError(f"{prefix} was stored outside the aggregate file ({tree}): {why}")
+    return tree
 
 
 def read_aggregate(path):
@@ -85,8 +161,7 @@ def read_aggregate(path):
     with open(fname, "rb") as f:
         tree = msgpack.unpackb(f.read(), ext_hook=_ext_hook, raw=False, strict_map_key=False)
     tree = _unchunk(tree)
-    _check_placeholders(tree)
-    return tree
+    return _resolve_placeholders(tree, path if os.path.isdir(path) else os.path.dirname(os.path.abspath(fname)))
 
 
 def _pack_default(x):

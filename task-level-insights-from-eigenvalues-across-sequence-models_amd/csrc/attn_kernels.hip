@@ -5,9 +5,14 @@
 //   1. qk_proj_kernel   : q,k = x Wqk^T + b (fp32, the v rows of Wqkv are never touched), optionally
 //                         phi = elu+1 fused; written once to the workspace as [B*L, 2*d_qk] fp32.
 //   2a. linattn_scan    : nu_t = phi(q_t) . sum_{s<=t} phi(k_s)  -- O(L), one wavefront per (b,h), fp64 state.
-//   2b. softmax_nu      : flash-style streaming over s-tiles, two passes per t-tile (row max, then
-//                         sum exp(fp32(score - m_t)) in fp64) so that the reference's fp32 max-subtraction
-//                         (eval_eig.py:62-74) and its masking quirks Q4/Q5 are reproduced exactly.
+//   2b. softmax_nu      : flash-style streaming over s-tiles.  The matrix-core kernel (softmax_nu_mfma_kernel) makes ONE
+//                         pass: running row maximum (initialised with quirk Q5's zero), subtracted in fp32 like
+//                         eval_eig.py:62-72; exp in fp32 with an exact range reduction (1.5e-7); fp64 row sums, rescaled
+//                         in fp64 when the maximum rises; masking quirks Q4 / Q5 in closed form.  Within the reference's
+//                         own fp32 error, NOT bit-faithful to its rounding (include/eigspec.h states the contract; NaN
+//                         and +-inf scores are outside it: fmaxf drops NaN where torch.max propagates it).  The VALU
+//                         twin (softmax_nu_kernel, head_dim % 4 != 0 or > 256) keeps the two-pass form: row maxima
+//                         first, then sum exp(fp32(score - m_t)) in fp64.
 //   3. eta_finalize     : eta_t = nu_t / nu_{t+1} [* exp(m_t - m_{t+1})], nu == 0 -> 2e-23 (linear, Q6).
 #include <type_traits>
 #include <stdlib.h>

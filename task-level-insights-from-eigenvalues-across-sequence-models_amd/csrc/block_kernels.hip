@@ -374,6 +374,17 @@ __global__ __launch_bounds__(256, 2) void linattn_chunk_mfma_kernel(
     float* Vr = Kr + 16 * kLdk;                                       // [16][128 + 16]
     float* w_in = Vr + 16 * kLdv;                                     // [2][16]
     float* nu_part = w_in + 32;                                       // [2][4][16]
+    float* Pp = nu_part + 128;                                        // [4][64][4] partial score tiles (kShareScore)
+    // Round 5: the 16 x 16 score tile of a chunk is the same for all four waves of the workgroup.  Each wave used to compute
+    // all of it (J MFMAs: a quarter of the kernel's excess over the algorithmic flops); now each wave contracts its QUARTER
+    // of the feature dimension (J / 4 MFMAs), the four partial tiles meet in LDS (one 16-byte store, four 16-byte reads per
+    // lane) and the barrier that publishes them sits behind the inter-chunk products (3), which do not need the tile.
+    // J < 16 keeps the per-wave form (a quarter would be less than one 16-byte operand step).
+#ifndef EGS_LINATTN_SCORE_PER_WAVE
+    constexpr bool kShareScore = J >= 16;
+#else
+    constexpr bool kShareScore = false;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int cchunks = (cpg + 127) / 128;
@@ -486,30 +497,26 @@ __global__ __launch_bounds__(256, 2) void linattn_chunk_mfma_kernel(
         fetch(t0 + 16 < L ? t0 + 16 : 0);
         if (t0 > 0) emit(t0 - 16, buf ^ 1);
 
-        // (1) transposed causal score tile
+        // (1) transposed causal score tile: all of it per wave, or this wave's quarter of the contraction
         f32x4 pa = {0.0f, 0.0f, 0.0f, 0.0f}, pb = {0.0f, 0.0f, 0.0f, 0.0f};
         {
             const float* kr = Kj + (g * 16 + c) * kLdj;
             const float* qr = Qj + (g * 16 + c) * kLdj;
+            constexpr int JW = kShareScore ? J / 4 : J;
+            const int j0 = kShareScore ? wv * JW : 0;
 #pragma unroll
-            for (int jj = 0; jj < J; jj += 4) {
-                const float4 k4 = *reinterpret_cast<const float4*>(kr + jj);
-                const float4 q4 = *reinterpret_cast<const float4*>(qr + jj);
+            for (int jj = 0; jj < JW; jj += 4) {
+                const float4 k4 = *reinterpret_cast<const float4*>(kr + j0 + jj);
+                const float4 q4 = *reinterpret_cast<const float4*>(qr + j0 + jj);
                 pa = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.x, q4.x, pa, 0, 0, 0);
                 pb = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.y, q4.y, pb, 0, 0, 0);
                 pa = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.z, q4.z, pa, 0, 0, 0);
                 pb = __builtin_amdgcn_mfma_f32_16x16x4f32(k4.w, q4.w, pb, 0, 0, 0);
             }
         }
-        float P[4];
-        float nu_intra = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            P[r] = (4 * g + r <= c) ? pa[r] + pb[r] : 0.0f;           // key s = 4 g + r, query t = c
-            nu_intra += P[r];
-        }
-        nu_intra += __shfl_xor(nu_intra, 16, 64);
-        nu_intra += __shfl_xor(nu_intra, 32, 64);
+        if (kShareScore)
+            *reinterpret_cast<float4*>(Pp + (wv * 64 + lane) * 4) =
+                make_float4(pa[0] + pb[0], pa[1] + pb[1], pa[2] + pb[2], pa[3] + pb[3]);
 
         // V operands of this lane: keys 4 kk + g (the same rows serve (2) with kk = r and (4))
         float vB[4][2];
@@ -520,17 +527,11 @@ __global__ __launch_bounds__(256, 2) void linattn_chunk_mfma_kernel(
         }
         f32x4 Y[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
         f32x4 NU = {0.0f, 0.0f, 0.0f, 0.0f};
-        // (2) intra-chunk: P register r holds keys 4 g + r; its V rows are Vr[4 g + r] -- NOT the vB rows (4 kk + g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v0 = Vr[(4 * g + r) * kLdv + col0];
-            const float v1 = Vr[(4 * g + r) * kLdv + col0 + 16];
-            Y[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], v0, Y[0], 0, 0, 0);
-            Y[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], v1, Y[1], 0, 0, 0);
-        }
+        // (3) inter-chunk, on the state as the previous chunks left it: A = q_t[16 dt + 4 g + r], B = S[dt] register r.
+        // Needs neither the score tile nor this chunk's state update, so it runs in front of the barrier that publishes
+        // the partial tiles.
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            // (3) inter-chunk: A = q_t[16 dt + 4 g + r], B = S[dt] register r
             const float4 q4 = *reinterpret_cast<const float4*>(Qr + c * kLdq + 16 * dt + 4 * g);
             const float qa[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
@@ -543,7 +544,41 @@ __global__ __launch_bounds__(256, 2) void linattn_chunk_mfma_kernel(
                 for (int r = 0; r < 4; ++r)
                     NU = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[r], KS[dt >> 2][r], NU, 0, 0, 0);
             }
-            // (4) state update: A = k_t[16 dt + c] for t = 4 kk + g, B = v_t
+        }
+        float P[4];
+        float nu_intra = 0.0f;
+        if (kShareScore) {
+            __syncthreads();                                          // the four partial tiles are in LDS
+            float4 sum = *reinterpret_cast<const float4*>(Pp + lane * 4);
+#pragma unroll
+            for (int x = 1; x < 4; ++x) {                             // fixed order: every wave forms the same tile
+                const float4 part = *reinterpret_cast<const float4*>(Pp + (x * 64 + lane) * 4);
+                sum.x += part.x;
+                sum.y += part.y;
+                sum.z += part.z;
+                sum.w += part.w;
+            }
+            pa = {sum.x, sum.y, sum.z, sum.w};
+            pb = {0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            P[r] = (4 * g + r <= c) ? pa[r] + pb[r] : 0.0f;           // key s = 4 g + r, query t = c
+            nu_intra += P[r];
+        }
+        nu_intra += __shfl_xor(nu_intra, 16, 64);
+        nu_intra += __shfl_xor(nu_intra, 32, 64);
+        // (2) intra-chunk: P register r holds keys 4 g + r; its V rows are Vr[4 g + r] -- NOT the vB rows (4 kk + g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v0 = Vr[(4 * g + r) * kLdv + col0];
+            const float v1 = Vr[(4 * g + r) * kLdv + col0 + 16];
+            Y[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], v0, Y[0], 0, 0, 0);
+            Y[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[r], v1, Y[1], 0, 0, 0);
+        }
+        // (4) state update: A = k_t[16 dt + c] for t = 4 kk + g, B = v_t
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const float a = Kr[(4 * kk + g) * kLdk + 16 * dt + c];
@@ -830,8 +865,8 @@ static int linattn_chunk_mfma_launch(const float* q, const float* k, int64_t bs,
                                      int64_t v_bs, int64_t v_ts, const float* w, float* y, int64_t batch, int64_t L,
                                      int channels, int groups, int cpg, int d, int phi, float kscale, int normalise,
                                      hipStream_t stream) {
-    const size_t dyn = ((size_t)2 * 4 * 16 * (J + 4) + 16 * (4 * J + 4) + 16 * (4 * J + 16) + 16 * (128 + 16) + 32 + 128) *
-                       sizeof(float);
+    const size_t dyn = ((size_t)2 * 4 * 16 * (J + 4) + 16 * (4 * J + 4) + 16 * (4 * J + 16) + 16 * (128 + 16) + 32 + 128 +
+                        4 * 64 * 4) * sizeof(float);
     if (dyn > 48 * 1024)
         EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_chunk_mfma_kernel<J>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));

@@ -1872,7 +1872,11 @@ __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
     // wave-uniform BY CONSTRUCTION, which the compiler cannot see through threadIdx: as a scalar, everything derived from
     // it (this wave's LDS halves, its scratch slot, its first matrix) lives in SGPRs instead of being spilled as
     // per-lane values across the register-hungry reduction
+#ifndef EGS_WAVE_VGPR
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+#else
+    const int wave = threadIdx.x / kWave;                           // rounds 2-4 (A/B: profiles/r05_variants.md)
+#endif
     double* base = smem_fused + (size_t)(wave >> 1) * kFusedPairDoubles;
     double* vecs = smem_fused + 2 * kFusedPairDoubles + (size_t)wave * kRegVec;
     const int64_t first = (int64_t)blockIdx.x * kFusedWaves + wave;

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(kRegWaves* kWave, 2) void hess_reg_kernel(const dou
                                                                         int32_t* __restrict__ scale_exp, int balance) {
     extern __shared__ __attribute__((aligned(16))) double smem_reg[];
     constexpr int n = 64;
-    const int wave = threadIdx.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);       // uniform by construction: a scalar
     const int64_t mat = (int64_t)blockIdx.x * kRegWaves + wave;
     if (mat >= nmat) return;                        // whole wave exits; no workgroup barriers are used
     RegLane L;

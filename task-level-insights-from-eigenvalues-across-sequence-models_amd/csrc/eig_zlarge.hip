@@ -53,7 +53,11 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
     __shared__ double red[kZLW];
     __shared__ zq s_alpha;
     __shared__ int s_idx;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // wave index as a scalar; thread index re-derived per panel from an opaque copy (see zmsqr_kernel): the per-lane
+    // addresses of the trailing update are then computed where they are used instead of being held -- spilled -- across
+    // the whole reduction
+    const int tid0 = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    int tid = tid0, lane = tid0 & 63;
     const int64_t mat = blockIdx.x;
     const int np = zl_np(n);
     const int ldv = np + 1;
@@ -252,6 +256,9 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
     // ---- panels ----
     const int rowtiles = np / 16;
     for (int k = 0; k < n - 2; k += NB) {
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
         const int jb = (NB < n - 2 - k) ? NB : (n - 2 - k);
         for (int idx = tid; idx < 2 * NB * ldv + NB * NB; idx += kZL) Vs[idx] = {0.0, 0.0};   // V, Y, T
         __syncthreads();
@@ -422,8 +429,10 @@ __global__ __launch_bounds__(kZL) void zhess_blocked_kernel(const double* __rest
             int cbn = kZLW / gw;                                      // concurrent column blocks
             if (cbn > 4) cbn = 4;
             const int grp = wv / gw, wi = wv - grp * gw;
-            const int cl = lane & 15, kk = lane >> 4;
             for (int cb0 = 0; cb0 < ncb; cb0 += cbn) {
+                int lane_c = lane;                                   // per column block, see the top of the kernel
+                asm volatile("" : "+v"(lane_c));
+                const int cl = lane_c & 15, kk = lane_c >> 4;
                 const bool wact = grp < cbn && cb0 + grp < ncb;
                 const int cbase = c0 + (cb0 + grp) * 16;
                 const int col = cbase + cl;
@@ -1221,13 +1230,20 @@ __device__ __forceinline__ void zapply_u(zq* __restrict__ H, int n, zq* __restri
 // prof: NULL, or double[nmat][12] receiving shader-clock cycles per phase (scan, shift generator / small blocks,
 // window load + store, chase, deferred updates, single-window chase), the sweep / stage counts, and the split of the
 // chase as wave 0 sees it (row phase, barrier, column phase, barrier).
+// PROF = false (the product instantiation): `prof` is ignored and none of the accumulators exists -- as run-time
+// optional state they were eleven 64-bit values live across the whole kernel, spilled at entry and reloaded inside the
+// sweep loop (profiles/r04_kernel_resources.json: 31 scratch instructions in loops).
+template <bool PROF>
 __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, int n, double* __restrict__ w,
-                                                    int32_t* __restrict__ info_out, double* __restrict__ prof,
+                                                    int32_t* __restrict__ info_out, double* __restrict__ prof_arg,
                                                     int zgeneral_only) {
+    double* const prof = PROF ? prof_arg : nullptr;
     extern __shared__ __attribute__((aligned(16))) double dynq[];
     __shared__ int s_idx;
     __shared__ int32_t s_info;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the wave index is uniform by construction; as a scalar, what is derived from it stays out of the vector registers
+    const int tid0 = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    int tid = tid0, lane = tid0 & 63;
     const int64_t mat = blockIdx.x;
     if (info_out[mat] != 0) return;                                   // non-finite input, flagged by the reduction
     zq* Wn = reinterpret_cast<zq*>(dynq);        // [QW][QLD]
@@ -1265,6 +1281,12 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
     }
     if (prof) plast = __builtin_readcyclecounter();
     while (i >= 0) {
+        // The chase / update bodies derive a dozen per-lane LDS addresses from the thread index; hoisted out of this loop they
+        // stay live -- spilled -- across it (128 registers per lane at 16 waves).  An opaque per-sweep copy keeps their
+        // derivation (a few integer instructions) inside the sweep.
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
         // ---- deflation scan: largest k in (0, i] with a negligible subdiagonal ----
         if (tid == 0) s_idx = 0;
         __syncthreads();
@@ -1472,11 +1494,18 @@ int zhess_blocked_launch(const void* a, bool in_real, int64_t nmat, int n, int l
 
 int zmsqr_launch(int64_t nmat, int n, double* w, int32_t* info, void* workspace, double* prof, hipStream_t stream) {
     const size_t dyn = ((size_t)2 * QW * QLD + QSMALL * QSLD + QM + QSMALL + 6 * QM + 6 * QM) * sizeof(zq);
-    EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zmsqr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)dyn));
     const int general_only = getenv("EGS_ZCHASE_GENERAL") ? 1 : 0;   // A/B switch: the general chase body in every stage
-    hipLaunchKernelGGL(zmsqr_kernel, dim3((unsigned)nmat), dim3(kZL), dyn, stream, static_cast<double*>(workspace), n, w,
-                       info, prof, general_only);
+    if (prof != nullptr) {
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zmsqr_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(zmsqr_kernel<true>, dim3((unsigned)nmat), dim3(kZL), dyn, stream, static_cast<double*>(workspace),
+                           n, w, info, prof, general_only);
+    } else {
+        EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zmsqr_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(zmsqr_kernel<false>, dim3((unsigned)nmat), dim3(kZL), dyn, stream, static_cast<double*>(workspace),
+                           n, w, info, prof, general_only);
+    }
     EGS_LAUNCH_CHECK();
     return 0;
 }

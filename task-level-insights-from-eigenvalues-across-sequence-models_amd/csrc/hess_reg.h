@@ -52,9 +52,17 @@ __device__ __forceinline__ double sum_c(double x) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(t, 1.0, 0.0, 0, 0, 0);
 }
 
-__device__ __forceinline__ double wave_max(double v) {
+// All-lanes maximum.  The partner addresses are derived from the caller's lane index (the fused kernel's per-matrix
+// OPAQUE copy): __shfl_xor derives them from the hardware lane id, which is invariant across the per-matrix loop -- the six
+// index vectors were hoisted out of it and spilled across the whole kernel.
+__device__ __forceinline__ double wave_max(double v, int lane) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    for (int off = 32; off > 0; off >>= 1) {
+        const int src = (lane ^ off) << 2;
+        const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+        const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+        v = fmax(v, __hiloint2double(hi, lo));
+    }
     return v;
 }
 
@@ -265,7 +273,7 @@ __device__ __forceinline__ int hess_reg_reduce(double (&A)[16][4], const RegLane
     // invariants; hoisted, they occupy ~150 registers across the whole reduction and are spilled.  Opaque copies keep
     // their computation here (16 multiply-adds per matrix) and in the rare path.
     asm volatile("" : "+s"(lda));
-    asm volatile("" : "+v"(scratch));
+    asm volatile("" : "+s"(scratch));          // wave-uniform (one slot per wave): stays in scalar registers
     double amax = 0.0;
     bool finite = true;
 #pragma unroll
@@ -284,7 +292,7 @@ __device__ __forceinline__ int hess_reg_reduce(double (&A)[16][4], const RegLane
     // only does this outside [1e-140, 1e140]; here every matrix is normalised so that the QR sweep can call a bulge
     // column negligible by an ABSOLUTE threshold (larfg3_coeffs in eig_real_lds.hip) before its squares underflow.
     if (scaling) {
-        amax = wave_max(amax);
+        amax = wave_max(amax, L.lane);
         if (__ballot(!finite) != 0ULL) e = kRegNonFinite;
         else if (amax > 0.0) e = ilogb(amax);
     }
@@ -321,19 +329,33 @@ __device__ __forceinline__ int hess_reg_reduce(double (&A)[16][4], const RegLane
             any_iso = __ballot(iso) != 0ULL;
         }
         if (any_iso) {
-            // through this wave's global-memory scratch, row-major
+            // through this wave's global-memory scratch, row-major.  ONE running pointer, bumped by four rows per step behind
+            // an opaque copy: with computed indices the compiler materialises eight 64-bit bases (the store offsets exceed
+            // the 12-bit immediate) on top of the 128 registers of A and spills -- in a branch almost never taken, but the
+            // spill slots and their reloads were the fused kernel's last scratch instructions
+            {
+                double* sp = scratch + L.q * n + L.c;
 #pragma unroll
-            for (int R = 0; R < 16; ++R)
+                for (int R = 0; R < 16; ++R) {
 #pragma unroll
-                for (int C = 0; C < 4; ++C) scratch[(4 * R + L.q) * n + 16 * C + L.c] = A[R][C];
+                    for (int C = 0; C < 4; ++C) sp[16 * C] = A[R][C];
+                    sp += 4 * n;
+                    asm volatile("" : "+v"(sp));
+                }
+            }
             __threadfence();
             permute_isolated(scratch, L.lane, k0, l0);
             __threadfence();
-            volatile const double* vs = scratch;
+            {
+                volatile const double* vs = scratch + L.q * n + L.c;
 #pragma unroll
-            for (int R = 0; R < 16; ++R)
+                for (int R = 0; R < 16; ++R) {
 #pragma unroll
-                for (int C = 0; C < 4; ++C) A[R][C] = vs[(4 * R + L.q) * n + 16 * C + L.c];
+                    for (int C = 0; C < 4; ++C) A[R][C] = vs[16 * C];
+                    vs += 4 * n;
+                    asm volatile("" : "+v"(vs));
+                }
+            }
         }
         const bool win = L.lane >= k0 && L.lane <= l0;
         for (int pass = 0; pass < 16; ++pass) {

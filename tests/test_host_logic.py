@@ -377,6 +377,92 @@ def test_orbax_chunked_arrays_and_placeholders(pkg, tmp_path):
         pkg.ckpt.read_aggregate(str(tmp_path / "nothing_here"))
 
 
+def test_orbax_zarr_v2_leaves_beside_the_aggregate_file(pkg, tmp_path):
+    """PARITY UNPINNED (no orbax / tensorstore / zarr in this image): parameters that orbax stored outside the aggregate
+    file as plain zarr v2 arrays -- a directory per leaf named by its flattened key path, ``.zarray`` JSON + chunk files --
+    built here from the published zarr v2 layout: C and F order, edge chunks at full chunk size, a missing chunk
+    (fill_value), big-endian data, zlib-compressed chunks, '/' as the dimension separator, a 0-d array; zstd (orbax's
+    usual codec) and OCDBT containers must fail loudly with the reason."""
+    import json
+    import zlib
+    root = tmp_path / "ck"
+    os.makedirs(root)
+
+    def write_zarr(name, arr, chunks, order="C", compressor=None, sep=".", skip=(), dtype=None):
+        d = root / name
+        os.makedirs(d)
+        dt = np.dtype(dtype or arr.dtype.str)
+        meta = {"zarr_format": 2, "shape": list(arr.shape), "chunks": list(chunks), "dtype": dt.str, "order": order,
+                "compressor": compressor, "filters": None, "fill_value": 0.0 if dt.kind == "f" else 0}
+        if sep != ".":
+            meta["dimension_separator"] = sep
+        (d / ".zarray").write_text(json.dumps(meta))
+        grid = [range((n + c - 1) // c) for n, c in zip(arr.shape, chunks)] if arr.ndim else []
+        import itertools
+        for idx in (itertools.product(*grid) if arr.ndim else [()]):
+            if idx in skip:
+                continue
+            block = np.zeros(chunks, dtype=dt)                    # edge chunks are stored at full chunk size
+            sel = tuple(slice(i * c, min((i + 1) * c, n)) for i, c, n in zip(idx, chunks, arr.shape))
+            view = arr[sel]
+            block[tuple(slice(0, v) for v in view.shape)] = view
+            raw = block.tobytes(order=order) if arr.ndim else np.asarray(arr, dtype=dt).tobytes()
+            if compressor is not None:
+                raw = zlib.compress(raw, 1)
+            fn = (d / sep.join(str(i) for i in idx)) if (sep == "." or not idx) else d.joinpath(*[str(i) for i in idx])
+            if not idx:
+                fn = d / "0"
+            os.makedirs(fn.parent, exist_ok=True)
+            fn.write_bytes(raw)
+
+    rng = np.random.default_rng(4)
+    lam = rng.standard_normal((10, 7)).astype(np.float32)
+    pz = rng.standard_normal((5, 6))
+    step = rng.standard_normal((9,)).astype(">f8")
+    hole = np.arange(12.0).reshape(3, 4)
+    write_zarr("model.params.encoder.layers_0.seq.Lambda_re", lam, (4, 3))                       # ragged edges, C order
+    write_zarr("model.params.encoder.layers_0.seq.P", pz, (2, 4), order="F", compressor={"id": "zlib", "level": 1})
+    write_zarr("model.params.encoder.layers_0.seq.log_step", step.astype(np.float64), (4,), dtype=">f8", sep="/")
+    write_zarr("model.params.hole", hole, (2, 2), skip={(1, 1)})
+    write_zarr("model.step", np.asarray(1200, dtype="<i8"), ())
+    ph = lambda k: "PLACEHOLDER://" + k
+    tree = {"model": {"params": {"encoder": {"layers_0": {"seq": {
+        "Lambda_re": ph("model.params.encoder.layers_0.seq.Lambda_re"), "P": ph("model.params.encoder.layers_0.seq.P"),
+        "log_step": ph("model.params.encoder.layers_0.seq.log_step"), "B": np.ones((2, 2))}}},
+        "hole": ph("model.params.hole")}, "step": ph("model.step")}}
+    pkg.ckpt.write_aggregate(str(root), tree)
+    back = pkg.ckpt.read_aggregate(str(root))
+    seq = back["model"]["params"]["encoder"]["layers_0"]["seq"]
+    np.testing.assert_array_equal(seq["Lambda_re"], lam)
+    assert seq["Lambda_re"].dtype == np.float32
+    np.testing.assert_array_equal(seq["P"], pz)
+    np.testing.assert_array_equal(seq["log_step"], step.astype(np.float64))
+    assert seq["log_step"].dtype.byteorder in ("=", "<", "|") and seq["log_step"].dtype == np.float64
+    want = hole.copy()
+    want[2:, 2:] = 0.0                                               # the unwritten chunk reads as fill_value
+    np.testing.assert_array_equal(back["model"]["params"]["hole"], want)
+    assert int(back["model"]["step"]) == 1200
+    np.testing.assert_array_equal(seq["B"], np.ones((2, 2)))
+    # get_trained_layers_ssm reaches the leaves through the same tree
+    layers = sys.modules[pkg.__name__ + ".analysis.eval_eig"].get_trained_layers_ssm(str(root))
+    np.testing.assert_array_equal(layers[0]["Lambda_re"], lam)
+    # codecs this environment cannot decode, and OCDBT, fail with the reason
+    z = tmp_path / "ckz"
+    os.makedirs(z / "w")
+    (z / "w" / ".zarray").write_text(json.dumps({"zarr_format": 2, "shape": [2], "chunks": [2], "dtype": "<f8", "order": "C",
+                                                 "compressor": {"id": "zstd", "level": 1}, "filters": None, "fill_value": 0}))
+    (z / "w" / "0").write_bytes(b"\x28\xb5\x2f\xfd")
+    pkg.ckpt.write_aggregate(str(z), {"w": ph("w")})
+    with pytest.raises(NotImplementedError, match="zstd"):
+        pkg.ckpt.read_aggregate(str(z))
+    o = tmp_path / "cko"
+    os.makedirs(o)
+    (o / "manifest.ocdbt").write_bytes(b"")
+    pkg.ckpt.write_aggregate(str(o), {"w": ph("w")})
+    with pytest.raises(NotImplementedError, match="OCDBT"):
+        pkg.ckpt.read_aggregate(str(o))
+
+
 def test_dropin_models_have_reference_parameter_names_and_no_cpu_path(pkg, golden):
     """CPU-side check of the drop-in models: state_dict keys equal the reference's (recorded in the goldens), and a
     forward on CPU tensors raises instead of falling back."""
