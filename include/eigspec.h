@@ -112,12 +112,12 @@ int egs_s4_cayley_map(const double* a, const int32_t* set_index, const double* l
  *   workspace : device scratch of egs_eig_workspace_bytes(dtype, nmat, n) bytes, 256-byte aligned.
  * Real n = 64 (BASELINE config C2) runs a fused kernel: per wavefront the Hessenberg reduction with the matrix in
  * registers, then the QR iteration in LDS, the whole batch behind one work queue; once a matrix's active block ends below
- * row 44 it is handed over (a 15.5 KB record per matrix in the workspace) to a second kernel that finishes it at twice the
+ * row 44 it is handed over (an 8.9 KB record per matrix in the workspace) to a second kernel that finishes it at twice the
  * occupancy -- same arithmetic, bit-identical spectra.  The workspace provides a 32 KB scratch slot per resident wavefront
  * plus those records; a smaller workspace than the query's value is accepted: records for >= min(nmat, 32768) matrices
  * give several passes, less gives the one-kernel form, which only needs the slots (it limits the number of resident
  * wavefronts, at least 4 slots + 256 bytes).  Spectra and info do not depend on the workspace size by a single bit; the
- * trade is memory against throughput (C2's 524288 matrices: 8.2 GB for one pass of the two-phase form; the Python
+ * trade is memory against throughput (C2's 524288 matrices: 4.8 GB for one pass of the two-phase form; the Python
  * binding halves its request down to 4096 matrices' worth when the allocation fails).  Other n <= 64, real or complex, run LDS-resident in two
  * kernels (one wavefront per matrix, Hessenberg matrices of a chunk in the workspace); larger n (<= 1024; the reference's S4
  * state_dim 128 / 512 and config C5's 256) run the level-3 path: blocked Householder reduction with fp64 matrix-core panel

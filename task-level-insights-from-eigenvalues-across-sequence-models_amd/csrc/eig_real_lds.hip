@@ -1762,7 +1762,7 @@ constexpr size_t kFusedLds = (size_t)(2 * kFusedPairDoubles + kFusedWaves * kReg
 // entries a chase leaves on the two diagonals below the sub-diagonal: the continuation is bit-identical to the
 // one-kernel iteration) plus its order and scaling exponent to a hand-off record in the workspace, and
 // hqr_tail_kernel finishes all of them at twice the occupancy (kTailN = 44: 16 waves per CU).
-// Hand-off record: kTailN x kTailN doubles, row-major, then {order of the remaining block (0 = nothing left), exponent}.
+// Hand-off record: {order of the remaining block (0 = nothing left), exponent}, then the packed rows (see kTailRec).
 // ---------------------------------------------------------------------------------------------------
 #ifndef EGS_TAIL_N
 #define EGS_TAIL_N 44
@@ -1770,7 +1770,17 @@ constexpr size_t kFusedLds = (size_t)(2 * kFusedPairDoubles + kFusedWaves * kReg
 constexpr int kTailN = EGS_TAIL_N;
 static_assert(kTailN % 2 == 0 && kTailN >= 34 && kTailN <= 56, "tail order: even (odd leading dimension), > 32 + bulge distance");
 constexpr int kTailLd = kTailN + 9;                              // odd; diagonal stride kTailLd + 1 spreads over >= 16 banks
-constexpr int kTailRec = kTailN * kTailN + 2;                    // doubles per hand-off record
+// Hand-off record, PACKED (round 5): {order of the remaining block, scaling exponent} and then, row by row, only what a
+// continuation reads -- row r holds columns max(0, r - 3) .. kTailN - 1 (the Hessenberg part and the two diagonals below
+// the sub-diagonal).  1118 doubles (8.9 KB) at kTailN = 44 instead of the 44 x 44 + 2 = 1938 (15.5 KB) of rounds 3-4:
+// the C2 workspace drops from 8.2 to 4.8 GB and the records' HBM traffic with it.
+__host__ __device__ constexpr int tail_row_off(int r) {
+    // doubles in front of row r: rows 0..3 are full, row r' >= 4 starts at column r' - 3
+    return r <= 4 ? r * kTailN : 4 * kTailN + (r - 4) * (kTailN + 3) - (r * (r - 1) / 2 - 6);
+}
+constexpr int kTailHdr = 2;
+constexpr int kTailRec = kTailHdr + tail_row_off(kTailN);        // doubles per hand-off record
+static_assert(tail_row_off(5) - tail_row_off(4) == kTailN - 1 && tail_row_off(4) == 4 * kTailN, "packed record offsets");
 #ifndef EGS_TAIL_WAVES
 #define EGS_TAIL_WAVES 4
 #endif
@@ -1786,11 +1796,12 @@ __device__ __forceinline__ void tail_handoff_write(const V H, const int rem, con
     const int c = (lane < kTailN) ? lane : kTailN - 1;
     for (int r = 0; r < rem; ++r) {
         const double v = H.at(r, c);
-        if (lane < rem && r <= lane + 3) rec[r * kTailN + lane] = v;
+        const int c0 = (r > 3) ? r - 3 : 0;
+        if (lane < rem && r <= lane + 3) rec[kTailHdr + tail_row_off(r) + lane - c0] = v;
     }
     if (lane == 0) {
-        rec[kTailN * kTailN] = (double)rem;
-        rec[kTailN * kTailN + 1] = (double)e;
+        rec[0] = (double)rem;
+        rec[1] = (double)e;
     }
 }
 
@@ -1800,13 +1811,18 @@ __device__ __forceinline__ void tail_handoff_read(const V H, const int rem, cons
     for (; r + 4 <= rem; r += 4) {
         double t[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = (lane < rem && r + u <= lane + 3) ? rec[(r + u) * kTailN + lane] : 0.0;
+        for (int u = 0; u < 4; ++u) {
+            const int c0 = (r + u > 3) ? r + u - 3 : 0;
+            t[u] = (lane < rem && r + u <= lane + 3) ? rec[kTailHdr + tail_row_off(r + u) + lane - c0] : 0.0;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (lane < rem && r + u <= lane + 3) H.at(r + u, lane) = t[u];
     }
-    for (; r < rem; ++r)
-        if (lane < rem && r <= lane + 3) H.at(r, lane) = rec[r * kTailN + lane];
+    for (; r < rem; ++r) {
+        const int c0 = (r > 3) ? r - 3 : 0;
+        if (lane < rem && r <= lane + 3) H.at(r, lane) = rec[kTailHdr + tail_row_off(r) + lane - c0];
+    }
 }
 
 __global__ __launch_bounds__(kTailWaves* kWave, 4) void hqr_tail_kernel(const double* __restrict__ handoff, int64_t nmat,
@@ -1823,9 +1839,9 @@ __global__ __launch_bounds__(kTailWaves* kWave, 4) void hqr_tail_kernel(const do
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const double* rec = handoff + mat * (int64_t)kTailRec;
-        const int rem = __builtin_amdgcn_readfirstlane((int)rec[kTailN * kTailN]);
+        const int rem = __builtin_amdgcn_readfirstlane((int)rec[0]);
         if (rem > 0 && rem <= kTailN) {
-            const int e = __builtin_amdgcn_readfirstlane((int)rec[kTailN * kTailN + 1]);
+            const int e = __builtin_amdgcn_readfirstlane((int)rec[1]);
             const double rescale = (e != 0) ? scalbn(1.0, e) : 1.0;
             double* wo = w + mat * 128;
             if ((wave & 1) == 0) {
@@ -1901,7 +1917,7 @@ __global__ __launch_bounds__(kFusedWaves* kWave, 2) void eig_real64_kernel(
             for (int j = lane; j < 2 * n; j += kWave) wo[j] = qnan;
             if (lane == 0) {
                 info[mat] = n;
-                if (handoff != nullptr) handoff[mat * (int64_t)kTailRec + kTailN * kTailN] = 0.0;
+                if (handoff != nullptr) handoff[mat * (int64_t)kTailRec] = 0.0;
             }
         } else {
             const double rescale = (e != 0) ? scalbn(1.0, e) : 1.0;

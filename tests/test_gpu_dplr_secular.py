@@ -108,6 +108,20 @@ def test_secular_path_full_c5_batch(gpu_ops):
     assert bool(torch.isfinite(torch.view_as_real(w)).all().item())
 
 
+def test_secular_path_grouping_of_partly_repeated_columns(gpu_ops):
+    """Columns are grouped by the BITS of (Lambda, P, Q): all equal (one solve), some equal (hashed groups, verified word
+    for word), none equal -- always the same spectra as without grouping, bit for bit."""
+    rng = np.random.default_rng(21)
+    n, h = 48, 9
+    lam_re, lam_im, p, _, ls = random_dplr(rng, n, h)
+    for rep in ([0] * h, [0, 1, 0, 1, 2, 2, 0, 3, 3], list(range(h))):
+        lr, li, pp = lam_re[rep], lam_im[rep], p[rep]
+        a = gpu_ops.s4_dplr_eigs(dev(lr), dev(li), dev(pp), dev(ls))
+        b = gpu_ops.s4_dplr_eigs(dev(lr), dev(li), dev(pp), dev(ls), dedupe=False)
+        assert int(a[1].abs().sum().item()) == 0 and int(b[1].abs().sum().item()) == 0
+        assert torch.equal(torch.view_as_real(a[0]), torch.view_as_real(b[0]))
+
+
 def test_secular_path_degenerate_inputs(gpu_ops):
     """Zero weights (P_k = 0: Lambda_k is an eigenvalue), exactly repeated poles (weights combine, the repeats are
     eigenvalues), a fully diagonal matrix (P = 0), and Q orthogonal to P elementwise-in-sum."""

@@ -352,7 +352,7 @@ def test_two_stage_api_on_unscaled_hessenberg_input(gpu_ops, scale):
 
 def test_workspace_falls_back_to_passes_under_memory_pressure(gpu_ops, monkeypatch):
     """ops._workspace halves its request down to the documented floor when the allocation fails (the n = 64 solver asks
-    for 15.5 KB per matrix of a pass): same spectra through the smaller workspace."""
+    for 8.9 KB per matrix of a pass): same spectra through the smaller workspace."""
     rng = np.random.default_rng(680)
     a = dev(rng.standard_normal((40000, 64, 64)) / 8)
     w_ref, info_ref = gpu_ops.eig_general_batched(a)

@@ -37,8 +37,23 @@ def counters(dirs):
     return out
 
 
+def _groups(durs, ratio=1.5):
+    """Split a kernel's launch durations where consecutive sorted values differ by more than `ratio`: bench.py launches
+    the same kernel on different batch sizes (the timed C2 batch and, e.g., the quarter-size Gaussian set), and one
+    average over both would describe neither."""
+    ds = sorted(durs)
+    out, cur = [], [ds[0]]
+    for v in ds[1:]:
+        if v > ratio * cur[-1]:
+            out.append(cur)
+            cur = []
+        cur.append(v)
+    out.append(cur)
+    return out
+
+
 def trace(d):
-    acc = {}
+    acc, meta = {}, {}
     for path in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
@@ -46,15 +61,18 @@ def trace(d):
                 if k is None:
                     continue
                 dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
-                a = acc.setdefault(k, [0, 0, 1 << 62, 0, row.get("VGPR_Count"), row.get("SGPR_Count"),
-                                       row.get("Scratch_Size"), row.get("LDS_Block_Size")])
-                a[0] += 1
-                a[1] += dur
-                a[2] = min(a[2], dur)
-                a[3] = max(a[3], dur)
+                acc.setdefault(k, []).append(dur)
+                meta[k] = [row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("Scratch_Size"), row.get("LDS_Block_Size")]
     print("Name,Calls,AverageNs,TotalDurationNs,MinNs,MaxNs,VGPR,SGPR,Scratch,LDS")
-    for k, a in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-        print(f'"{k}",{a[0]},{a[1] / a[0]:.0f},{a[1]},{a[2]},{a[3]},{a[4]},{a[5]},{a[6]},{a[7]}')
+    rows = []
+    for k, durs in acc.items():
+        gs = _groups(durs)
+        for gi, g in enumerate(sorted(gs, key=lambda g: -sum(g))):
+            # one row per duration group; a kernel launched on ONE problem size has one group and keeps its plain name
+            name = k if len(gs) == 1 else "%s [launch group %d of %d by duration]" % (k, gi + 1, len(gs))
+            rows.append((sum(g), name, len(g), sum(g) / len(g), min(g), max(g), meta[k]))
+    for tot, name, n, avg, lo, hi, m in sorted(rows, key=lambda r: -r[0]):
+        print(f'"{name}",{n},{avg:.0f},{tot},{lo},{hi},{m[0]},{m[1]},{m[2]},{m[3]}')
 
 
 if __name__ == "__main__":
