@@ -1351,6 +1351,13 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
             break;
         }
         // ---- shifts ----
+#ifdef EGS_ZSHIFT_REUSE
+        // experiment (profiles/r05_variants.md): every EGS_ZSHIFT_REUSE-th sweep of a stall sequence keeps the previous
+        // sweep's shifts instead of running the one-wave shift generator while fifteen waves wait
+        if (stall > 1 && (stall % EGS_ZSHIFT_REUSE) == 0 && stall % 6 != 0) {
+            // shifts[] still holds the previous sweep's
+        } else
+#endif
         if (stall % 6 == 0) {
             if (tid < QNS) {
                 const int j = i - QNS + 1 + tid;
@@ -1372,6 +1379,9 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
                 __syncthreads();
             }
         }
+#ifdef EGS_ZSHIFT_REUSE
+        if (!(stall > 1 && (stall % EGS_ZSHIFT_REUSE) == 0 && stall % 6 != 0))
+#endif
         if (tid < QM) shifts[tid] = sw[tid * QNS / QM];
         __syncthreads();
         ZSTAMP(pacc1)

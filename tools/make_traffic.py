@@ -18,6 +18,13 @@ sys.path.insert(0, ROOT)
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     nmat = int(sys.argv[3]) if len(sys.argv) > 3 else 524288
+    # launches of the n = 64 solver in one bench.py run, "count x matrices" each: the timed batch (1 warm-up + 3 steps + 4
+    # event-timed launches) and, since round 5, the quarter-size Gaussian set (1 + 3).  Bytes per matrix = bytes of ALL
+    # launches / matrices of ALL launches; the per-launch figure quoted for the timed batch is that x its matrix count.
+    plan = sys.argv[4] if len(sys.argv) > 4 else "8x%d,4x131072" % nmat
+    plan = [tuple(int(v) for v in part.split("x")) for part in plan.split(",")]
+    plan_launches = sum(c for c, _ in plan)
+    plan_matrices = sum(c * m for c, m in plan)
     import bench
     pmc = json.load(open(src))
     out = {"method": __doc__.split("\n\n")[1].replace("\n", " "), "source_pmc": src, "kernels": {}}
@@ -34,9 +41,16 @@ def main():
         base = short.split("<")[0]
         if base in bench.KERNEL_SOURCES:
             ent["source_sha"] = bench.kernel_source_sha(base)
-        if base in algo:
+        if base in ("eig_real64_kernel", "hqr_tail_kernel"):
+            if n != plan_launches:
+                raise SystemExit("%s: %d launches counted, the launch plan %s has %d" % (short, n, plan, plan_launches))
+            per_matrix = ent["hbm_bytes_per_launch"] * n / plan_matrices
+            ent["launch_plan"] = ["%d x %d matrices" % (c, m) for c, m in plan]
+            ent["hbm_bytes_per_launch_all_sizes_averaged"] = ent["hbm_bytes_per_launch"]
             ent["matrices_per_launch"] = nmat
-            ent["hbm_bytes_per_matrix"] = ent["hbm_bytes_per_launch"] / nmat
+            ent["hbm_bytes_per_matrix"] = per_matrix
+            ent["hbm_bytes_per_launch"] = per_matrix * nmat          # the timed batch's launches
+        if base in algo:
             ent["algorithmic_bytes_per_launch"] = algo[base]
             ent["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / algo[base]
         out["kernels"][short] = ent
