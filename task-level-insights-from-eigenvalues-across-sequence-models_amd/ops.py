@@ -266,7 +266,7 @@ def s4_dplr_eigs(lambda_re, lambda_im, p, log_step, q=None, clip=True, dedupe=Tr
             planes = [t[0:1].contiguous() for t in planes]
             set_index = torch.zeros((ncol,), dtype=torch.int32, device=lr.device)
         elif dedupe == "all" or dedupe is True:
-            mult = torch.arange(1, key.shape[1] + 1, device=lr.device, dtype=torch.int64) * 0x9E3779B97F4A7C15 % (1 << 62) | 1
+            mult = (torch.arange(1, key.shape[1] + 1, device=lr.device, dtype=torch.int64) * 0x1E3779B97F4A7C15) | 1   # odd, wraps
             h = (key * mult).sum(dim=1)                               # wrap-around int64 arithmetic: a hash, nothing more
             _, inverse = torch.unique(h, return_inverse=True)
             nuniq = int(inverse.max().item()) + 1
