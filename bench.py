@@ -310,9 +310,10 @@ def main():
     if rank == 0 and world == 1 and n == 64 and args.matrices == "s5":
         gaussian = gaussian_c2(ops, device, min(nmat, 131072), n, workspace)
     # ---- strong scaling's secondary line: config C4 (4096 sequences x 4096 tokens, D = 128) cut over the ranks ----
-    c4_strong = None
+    c4_strong, c5_strong = None, None
     if strong:
         c4_strong = c4_strong_scaling(ops, egs_dist, device, rank, world, backend)
+        c5_strong = c5_strong_scaling(ops, egs_dist, device, rank, world, backend)
 
     # ---- parity: GPU spectra vs the known spectrum and vs LAPACK on a sample ----
     info_bad = int((info != 0).sum().item())
@@ -344,7 +345,7 @@ def main():
             # of the communicator the collective ran on -- a SCALE record with N distinct uuids proves N GPUs took part
             "ranks": devices, "comm_size": (dist.get_world_size() if world > 1 else 1),
             "distinct_devices": len({d.get("uuid") or (d.get("host"), d.get("index")) for d in devices}),
-            "secondary_c2_gaussian": gaussian, "secondary_c4_strong": c4_strong,
+            "secondary_c2_gaussian": gaussian, "secondary_c4_strong": c4_strong, "secondary_c5_strong": c5_strong,
         }
         if cpu is not None:
             result["speedup_vs_cpu_1core"] = value / cpu["value"]
@@ -427,6 +428,46 @@ def c4_strong_scaling(ops, egs_dist, device, rank, world, backend):
     return {"workload": "C4: linear attention eta, B=4096, L=4096, D=128, d_qk=128, H=1, batch cut over %d rank(s)" % world,
             "scaling": "strong", "sequences_per_rank": hi - lo, "ms_per_step": el * 1e3, "eta_values_per_s": B * (L - 1) / el,
             "sequences_per_s": B / el, "gathered_shape": list(full.shape)}
+
+
+def c5_strong_scaling(ops, egs_dist, device, rank, world, backend):
+    """Config C5 as a strong-scaling line ("S4 HiPPO-init d_state=256 ... roofline fraction at 1/2/4/8 GPUs"): the 768
+    feature columns (6 layers x 128) cut over the ranks, fused DPLR build + dense complex solver on each slab, ONE
+    all-gather of the spectra; max over ranks.  One workgroup solves one matrix, so with fewer matrices than compute units
+    per rank (8 ranks: 96) the step is one matrix's latency: the fraction falls with N by construction."""
+    import oracle as O
+    n, h = 256, 768
+    lam, p, _, _, _ = O.make_dplr_hippo(n)
+    ls = np.random.default_rng(256).uniform(np.log(1e-3), np.log(1e-1), h)
+    lo, hi = egs_dist.shard_range(h, rank, world)
+    dd = lambda z: torch.from_numpy(np.ascontiguousarray(z)).to(device)
+    cnt = hi - lo
+    pr = (dd(np.tile(lam.real, (cnt, 1))), dd(np.tile(lam.imag, (cnt, 1))), dd(np.tile(p, (cnt, 1))), dd(ls[lo:hi]))
+
+    def step():
+        w, info = ops.eig_general_batched(ops.s4_dplr_build(*pr))
+        return (egs_dist.all_gather_slabs(w, h) if world > 1 else w), info
+    step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        full, info = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = (time.perf_counter() - t0) / 3
+    if world > 1:
+        tmax = torch.tensor([el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    tf = 4.0 * (40.0 / 3.0) * n ** 3 * h / el / 1e12
+    return {"workload": "C5: 768 HiPPO-DPLR complex128 256x256 matrices cut over %d rank(s), build + dense solve + gather" % world,
+            "scaling": "strong", "matrices_per_rank": cnt, "ms_per_step": el * 1e3, "spectra_per_s": h / el,
+            "achieved": tf, "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": tf / (FP64_PEAK_TFLOPS * world),
+            "unconverged_local": int((info != 0).sum().item()), "gathered_shape": list(full.shape)}
 
 
 def rehearse_launch(args, world, rank):

@@ -102,6 +102,9 @@ def test_bench_strong_scaling_splits_the_fixed_batch():
     assert d["unconverged"] == 0 and d["max_abs_dlambda_vs_lapack"] < 1e-5
     c4 = d["secondary_c4_strong"]
     assert c4["scaling"] == "strong" and c4["sequences_per_rank"] == 2048 and c4["gathered_shape"] == [4096, 4095, 1]
+    c5 = d["secondary_c5_strong"]
+    assert c5["scaling"] == "strong" and c5["matrices_per_rank"] == 384 and c5["gathered_shape"] == [768, 256]
+    assert c5["unconverged_local"] == 0 and abs(c5["frac"] - c5["achieved"] / c5["peak"]) < 1e-12
 
 
 def test_pipelined_all_gather_on_a_one_rank_rccl_group(tmp_path):
