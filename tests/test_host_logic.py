@@ -33,9 +33,12 @@ def test_workspace_queries_are_host_only(pkg):
     lib = pkg._capi.lib()
     c = pkg._capi
     # real n = 64, two-phase solver: a scratch slot per resident wave (256 CUs assumed without a device: 2048 waves), a
-    # hand-off record of 44 * 44 + 2 doubles per matrix, the queue counters
-    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 524288, 64) == 2048 * 64 * 64 * 8 + 524288 * (44 * 44 + 2) * 8 + 256
-    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 10, 64) == 12 * 64 * 64 * 8 + 10 * (44 * 44 + 2) * 8 + 256
+    # PACKED hand-off record per matrix (round 5): 2 header doubles + rows r of the 44 x 44 block from column max(0, r - 3)
+    # on = 4 * 44 + sum_{r=4}^{43} (47 - r) = 1116 doubles, the queue counters
+    rec = 2 + sum(44 - max(0, r - 3) for r in range(44))
+    assert rec == 1118
+    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 524288, 64) == 2048 * 64 * 64 * 8 + 524288 * rec * 8 + 256
+    assert lib.egs_eig_workspace_bytes(c.EGS_F64, 10, 64) == max(12 * 64 * 64 * 8 + 10 * rec * 8, 10 * 64 * 64 * 8) + 256
     assert lib.egs_eig_workspace_bytes(c.EGS_F64, 3, 64) == 3 * 64 * 64 * 8 + 256            # below one workgroup: two-kernel path
     assert lib.egs_eig_workspace_bytes(c.EGS_F64, 10, 48) == 10 * 48 * 48 * 8 + 256           # n < 64: Hessenberg scratch + queue
     assert lib.egs_eig_workspace_bytes(c.EGS_C128, 768, 256) == 768 * 256 * 256 * 16     # workgroup path: full copy
