@@ -111,6 +111,39 @@ def test_discrete_dplr_with_separate_p_and_q_matches_reference(golden):
         np.testing.assert_allclose(Cb, g[f"c{i}_Cb"], rtol=1e-9, atol=1e-10)
 
 
+def test_dplr_secular_prototype_matches_lapack_and_the_reference_golden(golden):
+    """The algorithm of the optional S4 fast path (csrc/dplr_secular.hip) on the CPU first: secular equation of
+    diag(Lambda) - P Q^H by Ehrlich-Aberth + Cayley map, against np.linalg.eigvals of the dense Ab (analysis/eval_eig.py:296),
+    the reference golden, and degenerate inputs (zero weights, repeated poles)."""
+    from oracle import dplr_secular_proto as S
+    rng = np.random.default_rng(41)
+    for n in (1, 2, 5, 16, 64, 128):
+        for pq in (False, True):
+            lam = -np.abs(rng.standard_normal(n)) - 0.1 + 1j * rng.standard_normal(n) * 5
+            p = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.2
+            q = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.2 if pq else None
+            a, its, bad = S.rank1_eigvals(lam, p, q)
+            assert bad == 0 and its < 120, (n, its)
+            ref = np.linalg.eigvals(np.diag(lam) - np.outer(p, np.conj(p if q is None else q)))
+            assert O.max_abs_dlambda(a, ref) < 1e-10, n
+    g = golden("ssm")
+    for i in range(2):
+        w, bad = S.s4_eigs(g[f"s4_{i}_Lambda_re"][:, 1], g[f"s4_{i}_Lambda_im"][:, 1], g[f"s4_{i}_P"][:, 1],
+                           float(np.exp(g[f"s4_{i}_log_step"][0, 1])))
+        assert bad == 0 and O.max_abs_dlambda(w, g[f"s4_{i}_eig"][:, 0]) < 1e-10
+    # zero weights and exactly repeated poles are eigenvalues as they stand
+    lam = np.array([-1.0 + 1j, -2.0, -1.0 + 1j, -0.5 - 2j, -2.0, -3.0])
+    p = np.array([0.3, 0.0, 0.4j, 0.2, 0.1, 0.0])
+    a, _, bad = S.rank1_eigvals(lam, p)
+    assert bad == 0 and O.max_abs_dlambda(a, np.linalg.eigvals(np.diag(lam) - np.outer(p, np.conj(p)))) < 1e-12
+    # raw HiPPO, N = 64: root by root backward stable although the spectrum itself is noise at this order
+    lam, p, _, _, _ = O.make_dplr_hippo(64)
+    a, its, bad = S.rank1_eigvals(lam, p)
+    A = np.diag(lam) - np.outer(p, p.conj())
+    nrm = np.linalg.norm(A, 2)
+    assert bad == 0 and max(np.linalg.svd(A - z * np.eye(64), compute_uv=False)[-1] for z in a[::4]) / nrm < 1e-13
+
+
 def test_s4_cayley_known_answer():
     """LAPACK-independent structure check: Ab = (g - A)^{-1} (g + A) with g = 2/step, so
     eig(Ab) = (g + a)/(g - a) for a in eig(A)."""
