@@ -1384,7 +1384,11 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
 #endif
         if (tid < QM) shifts[tid] = sw[tid * QNS / QM];
         __syncthreads();
+#ifdef EGS_ZPROF_GEN
+        ZSTAMP(pacc0)            // profiling variant: the shift generator goes to slot 0 (with the scan), slot 1 keeps the small blocks
+#else
         ZSTAMP(pacc1)
+#endif
         ++nsweep;
         const int tmax = (i - 1 - l) + 2 * (QM - 1);
         if (na <= QW) {
