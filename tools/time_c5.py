@@ -12,6 +12,10 @@ lam, p, _, _, _ = O.make_dplr_hippo(n)
 ls = np.random.default_rng(256).uniform(np.log(1e-3), np.log(1e-1), h)
 d = lambda z: torch.from_numpy(np.ascontiguousarray(z)).cuda()
 ab = ops.s4_dplr_build(d(np.tile(lam.real, (h, 1))), d(np.tile(lam.imag, (h, 1))), d(np.tile(p, (h, 1))), d(ls))
+if os.environ.get("KIND") == "randn":          # dense complex Gaussian matrices of the same order instead (A/B runs)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    ab = torch.complex(torch.randn((h, n, n), generator=g, device="cuda", dtype=torch.float64),
+                       torch.randn((h, n, n), generator=g, device="cuda", dtype=torch.float64)) / np.sqrt(2 * n)
 
 
 def med(fn, reps=3):
@@ -26,7 +30,7 @@ def med(fn, reps=3):
 
 w, info = ops.eig_general_batched(ab)
 ref = np.linalg.eigvals(ab[:4].cpu().numpy())
-out = {"lib": os.environ.get("EGS_LIB_PATH", "tree"), "eig_ms": med(lambda: ops.eig_general_batched(ab)),
+out = {"lib": os.path.basename(os.environ.get("EGS_LIB_PATH", "tree")), "kind": os.environ.get("KIND", "c5"), "eig_ms": med(lambda: ops.eig_general_batched(ab)),
        "unconverged": int((info != 0).sum().item()),
        "dlambda_sample": float(O.max_abs_dlambda(w[:4].cpu().numpy(), ref))}
 print(json.dumps(out))
