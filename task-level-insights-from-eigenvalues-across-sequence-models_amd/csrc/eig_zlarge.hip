@@ -1241,6 +1241,7 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
     extern __shared__ __attribute__((aligned(16))) double dynq[];
     __shared__ int s_idx;
     __shared__ int32_t s_info;
+    __shared__ int32_t s_binfo[QM];
     // the wave index is uniform by construction; as a scalar, what is derived from it stays out of the vector registers
     const int tid0 = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     int tid = tid0, lane = tid0 & 63;
@@ -1253,6 +1254,13 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
     zq* sw = shifts + QM;                        // [QSMALL] eigenvalues of a small block
     zq* prm = sw + QSMALL;                       // [2][QM][3] rotation parameters of the chase
     zq* mbx = prm + 6 * QM;                      // [2][QM][3] look-ahead mailbox
+    // Deflated blocks of <= QSMALL rows are independent problems for ONE wavefront each.  Solved where they appear they
+    // cost the whole workgroup that wave's latency (1.98 of 41.7 Mcycles per C5 matrix, fifteen waves waiting); so they
+    // are only RECORDED (start row, order) and solved after the iteration, sixteen at a time, one per wave, each on its
+    // own slab of the then idle window arrays (round 5).  Nothing touches their rows / columns in between: the
+    // eigenvalue-only iteration confines every update to the active block above them.
+    int* dlist = reinterpret_cast<int*>(mbx + 6 * QM);    // [kZDeferMax][2]
+    int ndefer = 0;
     zq* H = reinterpret_cast<zq*>(work) + mat * (int64_t)n * n;
     zq* wout = reinterpret_cast<zq*>(w) + mat * (int64_t)n;
     const int sexp = (int)w[mat * 2 * (int64_t)n];                   // scaling exponent left by the Hessenberg stage
@@ -1326,7 +1334,19 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
         const int na = i - l + 1;
         ZSTAMP(pacc0)
         if (na <= QSMALL) {
-            // ---- small deflated block: one wavefront finishes it ----
+#ifndef EGS_ZSMALL_INLINE
+            // ---- small deflated block: recorded, solved after the iteration (one wave per block, sixteen at a time) ----
+            if (tid == 0) {
+                dlist[2 * ndefer] = l;
+                dlist[2 * ndefer + 1] = na;
+            }
+            ++ndefer;                                                 // <= n / 2 entries (every block has >= 2 rows)
+            i = l - 1;
+            stall = 0;
+            ZSTAMP(pacc1)
+            continue;
+#else
+            // ---- small deflated block: one wavefront finishes it (rounds 2-4; A/B switch) ----
             for (int e = tid; e < na * na; e += kZL) {
                 const int c = e / na, r = e - c * na;
                 Ss[r * QSLD + c] = qsel(r <= c + 1, HG(l + r, l + c), zq{0.0, 0.0});
@@ -1345,6 +1365,7 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
             __syncthreads();
             ZSTAMP(pacc1)
             continue;
+#endif
         }
         if (++stall > 300) {
             info = i + 1;
@@ -1453,6 +1474,38 @@ __global__ __launch_bounds__(kZL) void zmsqr_kernel(double* __restrict__ work, i
             ZSTAMP(pacc4)
         }
     }
+#ifndef EGS_ZSMALL_INLINE
+    // ---- the recorded small blocks: wave w solves block 16 round + w on slab w of the window arrays ----
+    // (also when the iteration above gave up on a block: the recorded ones lie below it and are still valid problems)
+    if (ndefer > 0) {
+        __syncthreads();                                              // the list is complete and the windows are idle
+        if (tid == 0) s_info = 0;
+        if (tid < QM) s_binfo[tid] = 0;
+        __syncthreads();
+        zq* slab = (wv < 8 ? Wn : Un) + (wv & 7) * (QSMALL * QSLD);  // 8 slabs of 16 x 17 per window array
+        for (int b0 = 0; b0 < ndefer; b0 += QM) {
+            const int b = b0 + wv;
+            if (b < ndefer) {
+                const int bl = dlist[2 * b], bn = dlist[2 * b + 1];
+                for (int e = lane; e < bn * bn; e += kWave) {
+                    const int c = e / bn, r = e - c * bn;
+                    slab[r * QSLD + c] = qsel(r <= c + 1, HG(bl + r, bl + c), zq{0.0, 0.0});
+                }
+                wave_lds_sync();
+                // eigenvalues go straight to their slots of w (scaled back); a block that fails flags the matrix
+                zhqr_wave(ZViewT<0, false>{slab, QSLD}, bn, lane, reinterpret_cast<double*>(wout + bl), &s_binfo[wv], rescale);
+                wave_lds_sync();
+                if (lane == 0 && s_binfo[wv] != 0) {
+                    atomicMax(&s_info, bl + s_binfo[wv]);
+                    s_binfo[wv] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_info > info) info = s_info;
+        ZSTAMP(pacc1)
+    }
+#endif
     if (info != 0) {
         const double qnan = __longlong_as_double(0x7ff8000000000000LL);
         for (int j = tid; j < info; j += kZL) wout[j] = {qnan, qnan};
@@ -1507,7 +1560,8 @@ int zhess_blocked_launch(const void* a, bool in_real, int64_t nmat, int n, int l
 }
 
 int zmsqr_launch(int64_t nmat, int n, double* w, int32_t* info, void* workspace, double* prof, hipStream_t stream) {
-    const size_t dyn = ((size_t)2 * QW * QLD + QSMALL * QSLD + QM + QSMALL + 6 * QM + 6 * QM) * sizeof(zq);
+    const size_t dyn = ((size_t)2 * QW * QLD + QSMALL * QSLD + QM + QSMALL + 6 * QM + 6 * QM) * sizeof(zq) +
+                       (size_t)2 * 512 * sizeof(int);                 // + the list of deferred small blocks (n <= 1024)
     const int general_only = getenv("EGS_ZCHASE_GENERAL") ? 1 : 0;   // A/B switch: the general chase body in every stage
     if (prof != nullptr) {
         EGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(zmsqr_kernel<true>),
