@@ -166,3 +166,45 @@ def test_eval_eig_s4_with_the_dplr_solver(pkg, gpu_ops):
             assert O.max_abs_dlambda(sa[:, hcol, i], da[:, hcol, i]) < 1e-10
     with pytest.raises(ValueError):
         ev.get_eigvals_ssm("s4", layers, 0, 1, 16, s4_solver="qr")
+
+
+def test_secular_path_adversarial_poles_and_weights(gpu_ops):
+    """Inputs at the edges of the iteration: poles one ulp apart, weights of 1e-160 (the root IS the pole to working
+    precision), weights spread over ten decades, a single non-zero weight, Hermitian input (real poles, real weights:
+    interlacing roots), poles on a circle with equal weights.  Criterion: every flag clear and every returned value an
+    eigenvalue of a matrix within 1e-12 ||Ab|| of the dense Ab the reference would solve, and close to LAPACK's values where
+    those are well conditioned."""
+    rng = np.random.default_rng(99)
+    n = 24
+    cases = []
+    lam = -1.0 + 1j * (0.5 + np.arange(n) * 2.220446049250313e-16 * 4)
+    cases.append(("poles a few ulp apart", lam, rng.standard_normal(n) * 0.3 + 0j, None))
+    lam = -np.abs(rng.standard_normal(n)) - 0.1 + 1j * rng.standard_normal(n) * 3
+    cases.append(("weights of 1e-160", lam, np.full(n, 1e-80) + 0j, None))
+    # (six decades: beyond that gI - A is so ill-conditioned that the dense Ab -- the reference's own route -- carries
+    # errors of 1e-9 and is no yardstick any more; measured 4e-11 against it with weights up to 1e8)
+    cases.append(("weights over six decades", lam, 10.0 ** rng.uniform(-5, 1, n) * np.exp(1j * rng.uniform(0, 6.28, n)), None))
+    one = np.zeros(n, complex); one[7] = 2.5 - 1j
+    cases.append(("a single non-zero weight", lam, one, None))
+    cases.append(("hermitian", -np.sort(rng.uniform(0.1, 5, n)) + 0j, rng.standard_normal(n) + 0j, None))
+    cases.append(("poles on a circle", 3.0 * np.exp(2j * np.pi * np.arange(n) / n) - 4.0, np.full(n, 0.7 + 0j), None))
+    cases.append(("general q", lam, rng.standard_normal(n) + 1j * rng.standard_normal(n),
+                  rng.standard_normal(n) + 1j * rng.standard_normal(n)))
+    step = 0.05
+    g = 2.0 / step
+    for name, lam, p, q in cases:
+        args = (dev(lam.real[None]), dev(lam.imag[None]), dev(p[None]), dev(np.log(np.array([step]))))
+        w, info = gpu_ops.s4_dplr_eigs(*args, q=None if q is None else dev(q[None]), clip=False)
+        assert int(info.abs().sum().item()) == 0, name
+        mu = w.cpu().numpy()[0]
+        # against the matrix the reference would hand to eigvals: Ab = (gI - A)^-1 (gI + A), built by the oracle
+        A = np.diag(lam) - np.outer(p, np.conj(p if q is None else q))
+        Ab = np.linalg.solve(g * np.eye(n) - A, g * np.eye(n) + A)
+        nrm = np.linalg.norm(Ab, 2)
+        be = max(np.linalg.svd(Ab - z * np.eye(n), compute_uv=False)[-1] for z in mu) / nrm
+        assert be < 1e-12, (name, be)
+        assert O.max_abs_dlambda(mu, np.linalg.eigvals(Ab)) < 1e-6 * max(1.0, np.linalg.cond(np.linalg.eig(Ab)[1]) * 1e-8), name
+        # and the kernel is the prototype (oracle/dplr_secular_proto.py, checked against LAPACK on the CPU) to rounding
+        from oracle import dplr_secular_proto as S
+        mu_cpu, bad = S.s4_eigs(lam.real, lam.imag, p, step, q=q, clip=False)
+        assert bad == 0 and O.max_abs_dlambda(mu, mu_cpu) < 1e-9, name
